@@ -1,0 +1,215 @@
+"""Problem definition -> C-ABI descriptors.
+
+The reference reads an AMReX `inputs` file plus a Lua script
+(Source/MFP_config.cpp:40-356, defaults Source/default.lua:12-52).  Lua is not
+available in this image, so the same tables are given as a Python dict with the
+same keys: `states.<name>.{type,gas,reconstruction,flux,
+value,bc,div_transport,div_damping}`, `actions.<name>.{type,corner_transport,
+solver,states}`, the globals `cfl, time_integration_scheme, lightspeed, beta,
+skin_depth, Larmor, Debye` and the geometry keys of the inputs file.  Value
+entries are numbers or vectorised callables f(dat) with dat['x'|'y'|'z'].
+"""
+import math
+
+import numpy as np
+
+from . import abi, bc
+
+DEFAULTS = dict(lightspeed=-1.0, beta=1.0, skin_depth=1.0, Larmor=-1.0, Debye=-1.0, cfl=0.0,
+                time_integration_scheme="strang", force_dt=0.0)
+
+HYDRO_PRIM = ["rho", "x_vel", "y_vel", "z_vel", "p", "T", "gamma", "cp"]   # MFP_hydro.cpp:21-30
+FIELD_CONS = ["x_D", "y_D", "z_D", "x_B", "y_B", "z_B", "phi", "psi", "mu", "ep"]  # MFP_field.cpp:20-31
+FIELD_DEFAULT = {"phi": 0.0, "psi": 0.0, "mu": 1.0, "ep": 1.0}            # MFP_field.cpp:180-185
+
+
+def update_ref(cfg):
+    """MFP::update_ref (MFP_config.cpp:374-457): lightspeed, Larmor, Debye."""
+    g = dict(DEFAULTS)
+    g.update({k: cfg[k] for k in DEFAULTS if k in cfg})
+    c = g["lightspeed"]
+    if not c > 0:
+        raise ValueError("lightspeed must be set (ref_temp scaling is outside the built path)")
+    Larmor, Debye, beta, skin = g["Larmor"], g["Debye"], g["beta"], g["skin_depth"]
+    if Larmor > 0 and Debye > 0:                    # :420-421, case 1
+        skin = Debye * c
+        beta = 2 * (Larmor / skin) * (Larmor / skin)
+    elif beta > 0 and skin > 0:                     # case 2 :435-438
+        Debye = skin / c
+        Larmor = math.sqrt(beta / 2.0) * skin
+    else:
+        raise ValueError("plasma parameters not set")
+    return dict(lightspeed=c, Larmor=Larmor, Debye=Debye, beta=beta, skin_depth=skin)
+
+
+class Problem:
+    """Sorted states/actions and everything cmfp_create needs."""
+
+    def __init__(self, cfg, fp_mode=abi.FP_STRICT):
+        self.cfg = cfg
+        self.dim = int(cfg["dim"])
+        self.n_cell = [int(n) for n in cfg["n_cell"]] + [1] * (3 - self.dim)
+        self.prob_lo = [float(v) for v in cfg["prob_lo"]] + [0.0] * (3 - self.dim)
+        self.prob_hi = [float(v) for v in cfg["prob_hi"]] + [1.0] * (3 - self.dim)
+        self.periodic = [int(v) for v in cfg["is_periodic"]] + [0] * (3 - self.dim)
+        # Geometry::CellSize: (prob_hi - prob_lo) / n_cell
+        self.dx = [(self.prob_hi[d] - self.prob_lo[d]) / self.n_cell[d] for d in range(3)]
+        self.ref = update_ref(cfg)
+        self.cfl = float(cfg.get("cfl", DEFAULTS["cfl"]))
+        self.scheme = cfg.get("time_integration_scheme", DEFAULTS["time_integration_scheme"])
+        self.fp_mode = fp_mode
+        self.state_names = sorted(cfg["states"].keys())       # get_sorted_keys, MFP_config.cpp:102
+        self.action_names = sorted(cfg.get("actions", {}).keys())  # :261
+        self.state_index = {n: i for i, n in enumerate(self.state_names)}
+
+    # -- descriptors -----------------------------------------------------
+    def geometry(self, block_lo=None, block_n=None):
+        g = abi.Geometry()
+        g.dim = self.dim
+        for d in range(3):
+            g.n_cell[d] = self.n_cell[d]
+            g.prob_lo[d] = self.prob_lo[d]
+            g.dx[d] = self.dx[d]
+            g.is_periodic[d] = self.periodic[d]
+            g.block_lo[d] = 0 if block_lo is None else block_lo[d]
+            g.block_n[d] = self.n_cell[d] if block_n is None else block_n[d]
+        return g
+
+    def params(self):
+        p = abi.Params()
+        p.lightspeed = self.ref["lightspeed"]
+        p.Larmor = self.ref["Larmor"]
+        p.Debye = self.ref["Debye"]
+        p.cfl = self.cfl
+        p.time_integrator = abi.TIME_INTEGRATOR[self.scheme]
+        p.fp_mode = self.fp_mode
+        return p
+
+    def state_descs(self):
+        arr = (abi.StateDesc * len(self.state_names))()
+        for i, name in enumerate(self.state_names):
+            sd = self.cfg["states"][name]
+            d = arr[i]
+            d.reconstruction = abi.RECON[sd["reconstruction"]]
+            d.shock_threshold = -1.0
+            if sd["type"] == "hydro":
+                d.kind = abi.STATE_HYDRO
+                gas = sd["gas"]
+                if gas.get("type", "thermally_perfect") != "thermally_perfect":
+                    raise NotImplementedError("only the thermally_perfect gas is on the built path")
+                for key in ("mass", "charge", "gamma"):
+                    if isinstance(gas[key], (list, tuple)):
+                        raise NotImplementedError("multi-species (tracer) hydro states are not built yet")
+                d.mass, d.charge, d.gamma = float(gas["mass"]), float(gas["charge"]), float(gas["gamma"])
+                d.flux = abi.FLUX[sd["flux"]]
+                if d.flux == abi.FLUX["RankineHugoniot"]:
+                    raise ValueError("hydro state with a field flux")
+                if "shock_detector" in sd:
+                    if sd["shock_detector"].get("name") != "pressure_jump_detector":
+                        raise ValueError("unknown shock detector")
+                    d.shock_threshold = float(sd["shock_detector"]["threshold"])
+                table = bc.hydro_bc(sd.get("bc", {}), self.dim, self.periodic)
+            elif sd["type"] == "field":
+                d.kind = abi.STATE_FIELD
+                d.mass, d.charge, d.gamma = 1.0, 0.0, 1.0
+                if sd["flux"] != "RankineHugoniot":
+                    raise NotImplementedError("field 'HLLE' reads uninitialised memory in the reference "
+                                              "(SURVEY quirk Q4); only RankineHugoniot is built")
+                d.flux = abi.FLUX[sd["flux"]]
+                d.div_transport = float(sd.get("div_transport", 0.0))
+                d.div_damping = float(sd.get("div_damping", 0.0))
+                table = bc.field_bc(sd.get("bc", {}), self.dim, self.periodic)
+            else:
+                raise NotImplementedError(f"state type '{sd['type']}' is outside the built path")
+            for c in range(abi.MAX_COMP):
+                for dd in range(abi.MAX_DIM):
+                    for s in range(2):
+                        d.bc[c][dd][s] = table[c][dd][s]
+        return arr
+
+    def action_descs(self):
+        arr = (abi.ActionDesc * max(1, len(self.action_names)))()
+        for i, name in enumerate(self.action_names):
+            ad = self.cfg["actions"][name]
+            a = arr[i]
+            a.kind = abi.ACTION[ad["type"]]
+            a.corner_transport = int(bool(ad.get("corner_transport", True)))
+            a.solver = abi.SOLVER[ad.get("solver", "explicit")]
+            names = list(ad["states"])
+            idx = [self.state_index[n] for n in names]
+            if ad["type"] in ("plasma5", "Lorentz"):
+                kinds = [self.cfg["states"][n]["type"] for n in names]
+                species = [i2 for i2, k in zip(idx, kinds) if k == "hydro"]
+                field = [i2 for i2, k in zip(idx, kinds) if k == "field"]
+                if len(field) != 1:
+                    raise ValueError(f"action '{name}' needs exactly one field state")
+                idx = species + field       # species in list order, field last (MFP_plasma5.cpp:35-55)
+            a.n_states = len(idx)
+            for j, v in enumerate(idx):
+                a.states[j] = v
+        return arr
+
+    def n_comp(self, s):
+        return 5 if self.cfg["states"][self.state_names[s]]["type"] == "hydro" else 10
+
+    # -- initial data ----------------------------------------------------
+    def cell_centres(self, lo=None, n=None):
+        lo = [0, 0, 0] if lo is None else list(lo) + [0] * (3 - len(lo))
+        n = self.n_cell if n is None else list(n) + [1] * (3 - len(n))
+        ax = []
+        for d in range(3):
+            i = np.arange(lo[d], lo[d] + n[d], dtype=np.float64)
+            ax.append(self.prob_lo[d] + (i + 0.5) * self.dx[d])   # MFP_hydro.cpp:531-536
+        z, y, x = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+        return {"x": x, "y": y, "z": z, "t": 0.0}
+
+    @staticmethod
+    def _eval(v, dat, shape, default=0.0):
+        if v is None:
+            return np.full(shape, default)
+        if callable(v):
+            return np.broadcast_to(np.asarray(v(dat), dtype=np.float64), shape).copy()
+        return np.full(shape, float(v))
+
+    def initial_data(self, s, lo=None, n=None):
+        """Conserved initial data [comp][k][j][i] of state s on a block:
+        HydroState::init_data (MFP_hydro.cpp:504-567) with define_rho_p_T and
+        prim2cons (MFP_thermally_perfect_gas.cpp:248-269,220-246);
+        EulerianState::init_data for the field (MFP_eulerian.cpp:80-139)."""
+        sd = self.cfg["states"][self.state_names[s]]
+        dat = self.cell_centres(lo, n)
+        shape = dat["x"].shape
+        val = sd.get("value", {})
+        if sd["type"] == "field":
+            out = np.empty((10,) + shape)
+            for c, name in enumerate(FIELD_CONS):
+                out[c] = self._eval(val.get(name), dat, shape, FIELD_DEFAULT.get(name, 0.0))
+            return out
+        gas = sd["gas"]
+        m, g = float(gas["mass"]), float(gas["gamma"])
+        rho = self._eval(val.get("rho"), dat, shape) if "rho" in val else None
+        if rho is None and "nd" in val:                       # init_from_number_density, MFP_hydro.cpp:113-120
+            rho = self._eval(val["nd"], dat, shape) * m
+        if rho is None:
+            rho = np.zeros(shape)
+        u = self._eval(val.get("x_vel"), dat, shape)
+        v = self._eval(val.get("y_vel"), dat, shape)
+        w = self._eval(val.get("z_vel"), dat, shape)
+        p = self._eval(val.get("p"), dat, shape)
+        T = self._eval(val.get("T"), dat, shape)
+        # define_rho_p_T: fill the missing one of rho, p, T
+        a = (rho > 0) & (p > 0)
+        b = ~a & (p > 0) & (T > 0)
+        c = ~a & ~b & (rho > 0) & (T > 0)
+        rho = np.where(b, p * m / np.where(T != 0, T, 1.0), rho)
+        p = np.where(c, rho * T / m, p)
+        if np.any(rho <= 0) or np.any(p <= 0):
+            raise ValueError("Primitive values outside of physical bounds!!")
+        out = np.empty((5,) + shape)
+        out[0] = rho
+        out[1] = u * rho
+        out[2] = v * rho
+        out[3] = w * rho
+        ke = 0.5 * rho * (u * u + v * v + w * w)
+        out[4] = p / (g - 1) + ke
+        return out

@@ -1,0 +1,234 @@
+"""The BASELINE.json configurations as problem dicts (see config.py).
+
+Config 1 follows the reference's own input
+Exec/testing/Braginskii_Riemann_2F/problem_definition.lua:1-235 with the
+substitutions SURVEY.md §8(d) lists; configs 2-5 are authored here (the
+reference ships no KH / Orszag-Tang / GEM / 3-D RMI input) from the same
+section.  All initial data are analytic and deterministic.
+"""
+import math
+
+import numpy as np
+
+
+def brio_wu_two_fluid_1d(n=2048):
+    # problem_definition.lua:8-58 (dimensional bookkeeping that fixes Larmor, Debye)
+    mu_0_dim = 1.25663706e-6
+    kb = 1.38064852e-23
+    ref_lightspeed = 299792458.0
+    q_ref = 1.60217662e-19
+    m_ref = 1.6726219000e-27
+    lightspeed = 2000
+    ref_length = 1e-8
+    ref_mass = m_ref
+    ref_density = 1e31 * m_ref
+    beta = 1
+    mass_ratio = 100
+    ref_velocity = ref_lightspeed / lightspeed
+    n_ref = ref_density / ref_mass
+    B_ref = math.sqrt(2 * mu_0_dim * n_ref * ref_mass * ref_velocity * ref_velocity / beta)
+    ref_omega_c = q_ref * B_ref / ref_mass
+    ref_larmor_dim = ref_velocity / ref_omega_c
+    ref_skin_dim = ref_mass / (q_ref * math.sqrt(mu_0_dim * ref_density))
+    ref_skin_nd = ref_skin_dim / ref_length
+    Larmor = ref_larmor_dim / ref_length
+    Debye = ref_skin_nd / lightspeed
+
+    def step(A, B):
+        return lambda dat: np.where(dat["x"] <= 0.0, A, B)     # :107-113
+
+    hydro = lambda m, q, rs: {
+        "type": "hydro",
+        "gas": {"type": "thermally_perfect", "mass": m, "charge": q, "gamma": 5 / 3},
+        "reconstruction": "vanLeer", "flux": "HLLE",
+        "value": {"rho": step(1.0 * rs, 0.125 * rs), "x_vel": 0.0, "y_vel": 0.0, "z_vel": 0.0,
+                  "p": step(0.5, 0.05)},
+    }
+    return {
+        "dim": 1, "n_cell": [n], "prob_lo": [-2.0], "prob_hi": [2.0], "is_periodic": [0],
+        "cfl": 0.25, "time_integration_scheme": "strang",
+        "lightspeed": lightspeed, "Larmor": Larmor, "Debye": Debye,
+        "states": {
+            "ion": hydro(1.0, 1.0, 1.0),
+            "electron": hydro(1.0 / mass_ratio, -1.0, 1.0 / mass_ratio),
+            "field": {"type": "field", "reconstruction": "O6", "flux": "RankineHugoniot",
+                      "value": {"x_B": 0.75, "y_B": step(1.0, -1.0), "z_B": 0.0}},
+        },
+        "actions": {
+            "em_fluxes": {"type": "CTU", "corner_transport": True, "states": ["field"]},
+            "hydro_fluxes": {"type": "CTU", "corner_transport": True, "states": ["ion", "electron"]},
+            "plasma": {"type": "plasma5", "solver": "explicit", "states": ["ion", "electron", "field"]},
+        },
+    }
+
+
+def kelvin_helmholtz_2d(n=2048, flux="HLLC", recon="minmod"):
+    gam = 1.4
+    band = lambda dat: np.abs(dat["y"] - 0.5) < 0.25
+    return {
+        "dim": 2, "n_cell": [n, n], "prob_lo": [0.0, 0.0], "prob_hi": [1.0, 1.0], "is_periodic": [1, 1],
+        "cfl": 0.4, "time_integration_scheme": "strang", "lightspeed": 1.0,
+        "states": {
+            "fluid": {
+                "type": "hydro",
+                "gas": {"type": "thermally_perfect", "mass": 1.0, "charge": 0.0, "gamma": gam},
+                "reconstruction": recon, "flux": flux,
+                "value": {"rho": lambda d: np.where(band(d), 2.0, 1.0),
+                          "x_vel": lambda d: np.where(band(d), 0.5, -0.5),
+                          "y_vel": lambda d: 0.01 * np.sin(4 * math.pi * d["x"]),
+                          "z_vel": 0.0, "p": 2.5},
+            },
+        },
+        "actions": {"fluxes": {"type": "CTU", "corner_transport": True, "states": ["fluid"]}},
+    }
+
+
+def orszag_tang_two_fluid_2d(n=4096, solver="explicit", source="plasma5"):
+    gam = 5 / 3
+    c = 20.0
+    L = 2 * math.pi
+    nd = gam * gam
+    ux = lambda d: -np.sin(d["y"])
+    uy = lambda d: np.sin(d["x"])
+    Bx = lambda d: -np.sin(d["y"])
+    By = lambda d: np.sin(2 * d["x"])
+    # D = -(u x B)/c with u = (ux, uy, 0), B = (Bx, By, 0): only the z component is non-zero
+    Dz = lambda d: -(ux(d) * By(d) - uy(d) * Bx(d)) / c
+    hydro = lambda m, q: {
+        "type": "hydro",
+        "gas": {"type": "thermally_perfect", "mass": m, "charge": q, "gamma": gam},
+        "reconstruction": "minmod", "flux": "HLLC",
+        "value": {"rho": nd * m, "x_vel": ux, "y_vel": uy, "z_vel": 0.0, "p": gam / 2},
+    }
+    src = {"type": source, "states": ["ion", "electron", "field"]}
+    if source == "plasma5":
+        src["solver"] = solver
+    return {
+        "dim": 2, "n_cell": [n, n], "prob_lo": [0.0, 0.0], "prob_hi": [L, L], "is_periodic": [1, 1],
+        "cfl": 0.3, "time_integration_scheme": "strang",
+        "lightspeed": c, "skin_depth": 0.2, "beta": 1.0,
+        "states": {
+            "ion": hydro(1.0, 1.0),
+            "electron": hydro(1.0 / 25.0, -1.0),
+            "field": {"type": "field", "reconstruction": "O6", "flux": "RankineHugoniot",
+                      "div_transport": 1.0, "div_damping": 1.0,
+                      "value": {"x_B": Bx, "y_B": By, "z_B": 0.0, "x_D": 0.0, "y_D": 0.0, "z_D": Dz}},
+        },
+        "actions": {
+            "em_fluxes": {"type": "CTU", "corner_transport": True, "states": ["field"]},
+            "hydro_fluxes": {"type": "CTU", "corner_transport": True, "states": ["ion", "electron"]},
+            "plasma": src,
+        },
+    }
+
+
+def gem_reconnection_2d(nx=8192, ny=None):
+    """GEM challenge (Birn et al. 2001) two-fluid set-up, SURVEY.md §8(d) config 4."""
+    ny = nx // 2 if ny is None else ny
+    Lx, Ly = 25.6, 12.8
+    lam, B0, n0 = 0.5, 1.0, 1.0
+    mi, me = 1.0, 1.0 / 25.0
+    gam = 5 / 3
+    c = 20.0
+    Ti_Te = 5.0
+    # pressure balance: n0 (Ti + Te) = B0^2 / 2  (beta = 1 units)
+    Ttot = B0 * B0 / (2 * n0)
+    Te = Ttot / (1 + Ti_Te)
+    Ti = Ttot - Te
+    psi0 = 0.1
+    sech2 = lambda y: 1.0 / np.cosh(y / lam) ** 2
+    ndens = lambda d: n0 * (0.2 + sech2(d["y"]))
+    Bx = lambda d: (B0 * np.tanh(d["y"] / lam)
+                    - psi0 * (math.pi / Ly) * np.cos(2 * math.pi * d["x"] / Lx) * np.sin(math.pi * d["y"] / Ly))
+    By = lambda d: psi0 * (2 * math.pi / Lx) * np.sin(2 * math.pi * d["x"] / Lx) * np.cos(math.pi * d["y"] / Ly)
+    wall = {"lo": {"fill_hydro_bc": "slipwall"}, "hi": {"fill_hydro_bc": "slipwall"}}
+    fwall = {k: {"fill_D_bc": "asymmetry", "fill_B_bc": "asymmetry", "fill_phi_bc": "symmetry",
+                 "fill_psi_bc": "symmetry", "fill_mu_bc": "symmetry", "fill_ep_bc": "symmetry"} for k in ("lo", "hi")}
+    hydro = lambda m, q, T: {
+        "type": "hydro",
+        "gas": {"type": "thermally_perfect", "mass": m, "charge": q, "gamma": gam},
+        "reconstruction": "minmod", "flux": "HLLC",
+        "value": {"rho": lambda d: ndens(d) * m, "x_vel": 0.0, "y_vel": 0.0, "z_vel": 0.0,
+                  "p": lambda d: ndens(d) * T},
+        "bc": {"y": wall},
+    }
+    return {
+        "dim": 2, "n_cell": [nx, ny], "prob_lo": [-Lx / 2, -Ly / 2], "prob_hi": [Lx / 2, Ly / 2],
+        "is_periodic": [1, 0], "cfl": 0.3, "time_integration_scheme": "strang",
+        "lightspeed": c, "skin_depth": 1.0, "beta": 1.0,
+        "states": {
+            "ion": hydro(mi, 1.0, Ti),
+            "electron": hydro(me, -1.0, Te),
+            "field": {"type": "field", "reconstruction": "O6", "flux": "RankineHugoniot",
+                      "div_transport": 1.0, "div_damping": 1.0,
+                      "value": {"x_B": Bx, "y_B": By, "z_B": 0.0}, "bc": {"y": fwall}},
+        },
+        "actions": {
+            "em_fluxes": {"type": "CTU", "corner_transport": True, "states": ["field"]},
+            "hydro_fluxes": {"type": "CTU", "corner_transport": True, "states": ["ion", "electron"]},
+            "plasma": {"type": "plasma5", "solver": "explicit", "states": ["ion", "electron", "field"]},
+        },
+    }
+
+
+def richtmyer_meshkov_3d(n=512, ny=None, nz=None):
+    """3-D extension of Exec/testing/Thermal-RMI:
+    Mach-2 shock at x = -0.2, interface x = 0.1 cos(2 pi y) cos(2 pi z), density
+    1 -> 3, m_e/m_i = 0.01, without tracers / particles / elliptic."""
+    ny = n if ny is None else ny
+    nz = n if nz is None else nz
+    gam = 5 / 3
+    c, skin, beta = 20.0, 1.0, 1.0
+    mach = 2.0
+    p1, rho1 = 0.5, 1.0
+    a1 = math.sqrt(gam * p1 / rho1)
+    # Rankine-Hugoniot post-shock state for a shock moving in +x into (rho1, p1, u = 0)
+    p2 = p1 * (1 + 2 * gam / (gam + 1) * (mach * mach - 1))
+    rho2 = rho1 * ((gam + 1) * mach * mach) / ((gam - 1) * mach * mach + 2)
+    u2 = mach * a1 * (1 - rho1 / rho2)
+    width = 0.01
+    shock_x = -0.2
+
+    def interface(d):
+        return 0.1 * np.cos(2 * math.pi * d["y"]) * np.cos(2 * math.pi * d["z"])
+
+    def rho_nd(d):
+        x = d["x"]
+        light_heavy = 1.0 + 0.5 * (3.0 - 1.0) * (1 + np.tanh((x - interface(d)) / width))
+        return np.where(x < shock_x, rho2, light_heavy)
+
+    pres = lambda d: np.where(d["x"] < shock_x, p2, p1)
+    uvel = lambda d: np.where(d["x"] < shock_x, u2, 0.0)
+    hydro = lambda m, q: {
+        "type": "hydro",
+        "gas": {"type": "thermally_perfect", "mass": m, "charge": q, "gamma": gam},
+        "reconstruction": "minmod", "flux": "HLLC",
+        "value": {"rho": lambda d: rho_nd(d) * m, "x_vel": uvel, "y_vel": 0.0, "z_vel": 0.0,
+                  "p": lambda d: 0.5 * pres(d)},
+    }
+    return {
+        "dim": 3, "n_cell": [n, ny, nz], "prob_lo": [-0.5, 0.0, 0.0],
+        "prob_hi": [-0.5 + 1.0 * n / max(ny, 1), 1.0, 1.0 * nz / max(ny, 1)],
+        "is_periodic": [0, 1, 1], "cfl": 0.3, "time_integration_scheme": "strang",
+        "lightspeed": c, "skin_depth": skin, "beta": beta,
+        "states": {
+            "ion": hydro(1.0, 1.0),
+            "electron": hydro(0.01, -1.0),
+            "field": {"type": "field", "reconstruction": "O6", "flux": "RankineHugoniot",
+                      "div_transport": 1.0, "div_damping": 1.0, "value": {}},
+        },
+        "actions": {
+            "em_fluxes": {"type": "CTU", "corner_transport": True, "states": ["field"]},
+            "hydro_fluxes": {"type": "CTU", "corner_transport": True, "states": ["ion", "electron"]},
+            "plasma": {"type": "plasma5", "solver": "explicit", "states": ["ion", "electron", "field"]},
+        },
+    }
+
+
+WORKLOADS = {
+    "brio_wu_1d": brio_wu_two_fluid_1d,
+    "kh_2d": kelvin_helmholtz_2d,
+    "ot2f_2d": orszag_tang_two_fluid_2d,
+    "gem_2d": gem_reconnection_2d,
+    "rmi_3d": richtmyer_meshkov_3d,
+}

@@ -1,0 +1,259 @@
+/*
+ * cerberus_mfp.h — C ABI of the MI355X-native per-patch hyperbolic update
+ * (five-moment multi-fluid + Maxwell) that replaces the hot path of
+ * PlasmaSimUQ/cerberus (MFP).
+ *
+ * The reference has no FFI: the path sits behind its C++ State/Action plugin
+ * API.  Every entry point below names the reference interface it replaces
+ * (file:line relative to the reference tree).  All functions return 0 on
+ * success and a negative cmfp_status otherwise; cmfp_last_error() gives the
+ * text.  Nothing C++ and no torch type crosses this boundary: plain pointers,
+ * sizes and POD descriptors only.  State arrays stay resident in HBM between
+ * calls; one host thread per context.
+ */
+#ifndef CERBERUS_MFP_H
+#define CERBERUS_MFP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMFP_MAX_DIM 3
+#define CMFP_MAX_COMP 10
+#define CMFP_MAX_ACTION_STATES 8
+
+typedef enum {
+    CMFP_OK = 0,
+    CMFP_ERR_INVALID = -1,  /* bad argument / unsupported option           */
+    CMFP_ERR_HIP = -2,      /* a HIP runtime call failed                    */
+    CMFP_ERR_PHYSICS = -3,  /* rho, p or T <= 0 on device: the reference's  */
+                            /* "Primitive values outside of physical        */
+                            /* bounds!!" abort (MFP_hydro_gas.cpp:152-164)  */
+    CMFP_ERR_NODEVICE = -4  /* no HIP device / extension not usable         */
+} cmfp_status;
+
+/* State kinds: tags "hydro" (hydro/MFP_hydro.cpp:51) and "field"
+ * (field/MFP_field.cpp:42). */
+typedef enum { CMFP_STATE_HYDRO = 0, CMFP_STATE_FIELD = 1 } cmfp_state_kind;
+
+/* Reconstruction tags (MFP_reconstruction.cpp:51,73,115,155,208,239,275). */
+typedef enum {
+    CMFP_RECON_CONSTANT = 0,
+    CMFP_RECON_MINMOD = 1,
+    CMFP_RECON_VANLEER = 2,
+    CMFP_RECON_MC = 3,
+    CMFP_RECON_CENTRE = 4,
+    CMFP_RECON_O6 = 5,
+    CMFP_RECON_WENO = 6
+} cmfp_recon;
+
+/* Riemann solver tags: hydro "HLLC" (MFP_hllc.cpp:6), "HLLE"
+ * (MFP_hydro_hlle.cpp:8), "HLLE/HLLC" (MFP_hybrid_hll.cpp:9); field
+ * "RankineHugoniot" (MFP_field_RH.cpp:11). */
+typedef enum {
+    CMFP_FLUX_HLLC = 0,
+    CMFP_FLUX_HLLE = 1,
+    CMFP_FLUX_HYBRID_HLL = 2,
+    CMFP_FLUX_FIELD_RH = 10
+} cmfp_flux;
+
+/* Mathematical ghost-cell rule per component and domain face; the numeric
+ * values are amrex::BCType's (listed in modules/boundary/MFP_fillbc.cpp:100-109).
+ * The map physical-BC-name -> these codes (modules/boundary/MFP_bc.cpp:11-31,
+ * 99-109) is host-side logic (cerberus_amd/bc.py, cerberus_amd/host). */
+typedef enum {
+    CMFP_BC_BOGUS = -666,
+    CMFP_BC_REFLECT_ODD = -1,
+    CMFP_BC_INT_DIR = 0,
+    CMFP_BC_REFLECT_EVEN = 1,
+    CMFP_BC_FOEXTRAP = 2,
+    CMFP_BC_EXT_DIR = 3,
+    CMFP_BC_HOEXTRAP = 4
+} cmfp_bc;
+
+/* Action tags "CTU" (MFP_CTU_hydro.cpp:10), "plasma5" (MFP_plasma5.cpp:9),
+ * "Lorentz" (MFP_lorentz.cpp). */
+typedef enum { CMFP_ACTION_CTU = 0, CMFP_ACTION_PLASMA5 = 1, CMFP_ACTION_LORENTZ = 2 } cmfp_action_kind;
+
+typedef enum { CMFP_SOLVER_EXPLICIT = 0, CMFP_SOLVER_IMPLICIT = 1 } cmfp_source_solver;
+
+/* time_integration_scheme (MFP_config.cpp:71-87). */
+typedef enum { CMFP_TI_EULER = 0, CMFP_TI_RK2 = 1, CMFP_TI_STRANG = 2 } cmfp_time_integrator;
+
+/* Kernel floating-point contraction mode.  STRICT: no FMA contraction, the
+ * expression order of the reference (bit-comparable with a g++ build of the
+ * same expressions).  FAST: the same kernels compiled with FMA contraction
+ * (documented difference, must stay within 1e-12 relative of STRICT). */
+typedef enum { CMFP_FP_STRICT = 0, CMFP_FP_FAST = 1 } cmfp_fp_mode;
+
+/* Uniform single-level geometry (AMReX inputs geometry.*, amr.n_cell) plus the
+ * block of it this context owns (one block per GPU). */
+typedef struct {
+    int dim;                        /* AMREX_SPACEDIM: 1, 2 or 3                */
+    int n_cell[CMFP_MAX_DIM];       /* global cells (amr.n_cell)                */
+    double prob_lo[CMFP_MAX_DIM];   /* geometry.prob_lo                         */
+    double dx[CMFP_MAX_DIM];        /* cell size                                */
+    int is_periodic[CMFP_MAX_DIM];  /* geometry.is_periodic                     */
+    int block_lo[CMFP_MAX_DIM];     /* first global cell index of this block    */
+    int block_n[CMFP_MAX_DIM];      /* cells of this block                      */
+} cmfp_geometry;
+
+/* Global scalars: MFP::lightspeed, Larmor, Debye (MFP_config.cpp:374-457),
+ * cfl (MFP_config.cpp:188), the integrator (MFP_config.cpp:71-87). */
+typedef struct {
+    double lightspeed;
+    double Larmor;
+    double Debye;
+    double cfl;
+    int time_integrator; /* cmfp_time_integrator */
+    int fp_mode;         /* cmfp_fp_mode          */
+} cmfp_params;
+
+/* One Eulerian state, in the reference's sorted-name order
+ * (MFP_config.cpp:102-139).  hydro: states.<name>.{gas,reconstruction,flux,
+ * shock_detector} (MFP_hydro.cpp:296-442); field: {reconstruction,flux,
+ * div_transport,div_damping} (MFP_field.cpp:273-403). */
+typedef struct {
+    int kind;           /* cmfp_state_kind */
+    int reconstruction; /* cmfp_recon      */
+    int flux;           /* cmfp_flux       */
+    double mass;        /* gas.mass   (single species)                         */
+    double charge;      /* gas.charge                                          */
+    double gamma;       /* gas.gamma                                           */
+    double shock_threshold; /* shock_detector.threshold (<=0: none)            */
+    double div_transport;   /* field: c_h / c                                  */
+    double div_damping;     /* field                                           */
+    /* BCRec per conserved component: bc[comp][dim][0=lo,1=hi] (cmfp_bc).
+     * hydro uses comps 0..4, field 0..9. */
+    int bc[CMFP_MAX_COMP][CMFP_MAX_DIM][2];
+} cmfp_state_desc;
+
+/* One action, in sorted-name order (MFP_config.cpp:261-291). */
+typedef struct {
+    int kind;             /* cmfp_action_kind                                   */
+    int corner_transport; /* CTU: 'corner_transport' (MFP_CTU_hydro.cpp:23)      */
+    int solver;           /* plasma5: cmfp_source_solver (MFP_plasma5.cpp:22-31) */
+    int n_states;
+    /* CTU: the states it transports.  plasma5/Lorentz: species in the order
+     * of the Lua 'states' list, then the field last. */
+    int states[CMFP_MAX_ACTION_STATES];
+} cmfp_action_desc;
+
+typedef struct cmfp_context cmfp_context;
+
+/* Library / device probe.  cmfp_version: build string.  cmfp_device_count:
+ * number of HIP devices visible (0 => every compute entry point fails with
+ * CMFP_ERR_NODEVICE; there is no CPU fallback). */
+const char* cmfp_version(void);
+int cmfp_device_count(void);
+
+/* Builds the per-GPU solver: replaces MFP::variableSetUp + read_config
+ * (MFP_setup.cpp:7, MFP_config.cpp:40-356) for the objects on the path.
+ * `device` is the HIP device ordinal, `stream` a hipStream_t (NULL = default
+ * stream) on which every kernel of this context is launched. */
+int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_states,
+                const cmfp_state_desc* states, int n_actions, const cmfp_action_desc* actions,
+                int device, void* stream, cmfp_context** out);
+int cmfp_destroy(cmfp_context* ctx);
+const char* cmfp_last_error(const cmfp_context* ctx);
+
+/* Number of conserved comps / ghost width (Reconstruction::num_grow,
+ * MFP_reconstruction.cpp:60,82,124,164,217,248,284) of a state. */
+int cmfp_state_ncomp(const cmfp_context* ctx, int state);
+int cmfp_state_ngrow(const cmfp_context* ctx, int state);
+
+/* State data host <-> HBM: replaces EulerianState::init_data's store into the
+ * new-time MultiFab (MFP_eulerian.cpp:80-139) and a plotfile read-back.  Host
+ * layout: valid cells of this block only, [comp][k][j][i], i fastest. */
+int cmfp_state_upload(cmfp_context* ctx, int state, const double* host);
+int cmfp_state_download(cmfp_context* ctx, int state, double* host);
+/* Zero-copy view of the HBM-resident new-time data: base pointer of the
+ * ghosted SoA array, ghost width and padded extents (i fastest, comp slowest:
+ * the FArrayBox layout). */
+int cmfp_state_device_view(cmfp_context* ctx, int state, double** dptr, int* ngrow,
+                           long long extent[CMFP_MAX_DIM], int* ncomp);
+
+/* ---- Action plugin API, one call per virtual of class Action
+ * (actions/MFP_action.H:60-90).  They act on the context's UpdateData
+ * {U, dU, status} per state (actions/MFP_action.H:16-29), owned by the
+ * library for the duration of one cmfp_advance-equivalent sequence started
+ * with cmfp_update_begin. */
+int cmfp_update_begin(cmfp_context* ctx); /* Vector<UpdateData> RK_step(...) (MFP_advance.cpp:62,141) */
+/* Action::get_data (MFP_action.cpp:15-102; HydroCTU::get_data
+ * MFP_CTU_hydro.cpp:43-52; Plasma5::get_data MFP_plasma5.cpp:60-71). */
+int cmfp_action_get_data(cmfp_context* ctx, int action, double time);
+/* Action::calc_time_derivative (Plasma5: MFP_plasma5.cpp:73-455, Lorentz:
+ * MFP_lorentz.cpp:60-198). */
+int cmfp_action_calc_time_derivative(cmfp_context* ctx, int action, double time, double dt);
+/* HydroCTU::calc_spatial_derivative (MFP_CTU_hydro.cpp:54-532). */
+int cmfp_action_calc_spatial_derivative(cmfp_context* ctx, int action, double time, double dt,
+                                        double flux_register_scale);
+/* Action::get_allowed_time_step (Plasma5: MFP_plasma5.cpp:457-567). */
+int cmfp_action_get_allowed_time_step(cmfp_context* ctx, int action, double* dt);
+/* EulerianState::get_allowed_time_step (MFP_eulerian.cpp:255-311),
+ * FieldState::get_allowed_time_step (MFP_field.cpp:57-67). */
+int cmfp_state_get_allowed_time_step(cmfp_context* ctx, int state, double* dt);
+/* Read back dU / U of one state's UpdateData (valid cells, host layout as
+ * cmfp_state_upload) — test and debugging aid. */
+int cmfp_update_download(cmfp_context* ctx, int state, int which /*0=U,1=dU*/, double* host);
+
+/* ---- Level API.
+ * cmfp_est_time_step: MFP::estTimeStep (MFP_timestep.cpp:4-21) for this
+ * block, without the cross-rank ReduceRealMin (the caller does it: RCCL min).
+ * cmfp_compute_new_dt: the growth cap of MFP::computeNewDt
+ * (MFP_timestep.cpp:86-93) applied to an already-reduced estimate.
+ * cmfp_advance: MFP::advance (MFP_advance.cpp:6-56) incl. advance_RK /
+ * advance_strang (MFP_advance.cpp:58-289). */
+int cmfp_est_time_step(cmfp_context* ctx, double* dt);
+double cmfp_compute_new_dt(double est_dt, double old_dt);
+int cmfp_advance(cmfp_context* ctx, double time, double dt);
+/* Uses hand-fused kernels inside cmfp_advance where available (default 1);
+ * 0 forces the stage-by-stage kernels that mirror the reference's FAB-level
+ * functions one to one.  Results are identical. */
+int cmfp_set_fused(cmfp_context* ctx, int enable);
+
+/* ---- Ghost cells: the FillPatch of Action::get_data (MFP_action.cpp:59) ->
+ * FillBC::operator() -> fab_filcc (modules/boundary/MFP_fillbc.cpp:147-172).
+ * Dimension d of the new-time data of `state` is filled over the full extent
+ * of the lower dimensions' ghosts.  Where this block spans the whole domain in
+ * d the library fills it itself (periodic wrap or the bc[] rule).  Where the
+ * domain is split in d between ranks, the library calls the registered
+ * exchange callback, which must move the packed faces between neighbours
+ * (cmfp_halo_pack / cmfp_halo_unpack give and take contiguous device
+ * buffers); physical faces on the outer ranks are still filled by the
+ * library. */
+typedef int (*cmfp_exchange_fn)(void* user, cmfp_context* ctx, int state, int dim);
+int cmfp_set_exchange_callback(cmfp_context* ctx, cmfp_exchange_fn fn, void* user);
+int cmfp_fill_patch(cmfp_context* ctx, int state);
+/* Number of doubles in one packed face of `state` normal to `dim`. */
+long long cmfp_halo_count(const cmfp_context* ctx, int state, int dim);
+/* side 0: pack the ng valid layers next to the low face (to send to the low
+ * neighbour); side 1: next to the high face.  Unpack side 0 writes the low
+ * ghost layers, side 1 the high ghost layers.  dbuf is device memory. */
+int cmfp_halo_pack(cmfp_context* ctx, int state, int dim, int side, double* dbuf);
+int cmfp_halo_unpack(cmfp_context* ctx, int state, int dim, int side, const double* dbuf);
+
+/* ---- Leaf numerics on device, batched over n independent inputs (SoA:
+ * component c of item i at [c*n + i]); device pointers.  They run the very
+ * device functions the update kernels call, so the leaves can be pinned
+ * against known-answer vectors directly.
+ * Reconstruction::get_slope / get_face_values (MFP_reconstruction.H:17-18):
+ * stencil has stencil_length(recon) comps. */
+int cmfp_leaf_reconstruct(int recon, int fp_mode, long long n, const double* stencil,
+                          double* slope, double* lo, double* hi, void* stream);
+/* RiemannSolver::solve (MFP_eulerian_riemann.H:23): hydro L,R have 8 comps
+ * {rho,u,v,w,p,T,gamma,cp}, F 5; field L,R,F have 10 (c0 = lightspeed,
+ * ch = div_speed). */
+int cmfp_leaf_riemann(int flux, int fp_mode, long long n, const double* L, const double* R,
+                      double* F, double c0, double ch, double shock_threshold, void* stream);
+/* HydroGas::cons2prim / prim2cons / get_speed_from_cons
+ * (MFP_thermally_perfect_gas.cpp:180-246,294-317): U 5 comps, Q 8, speeds 3. */
+int cmfp_leaf_cons2prim(int fp_mode, long long n, double mass, double gamma, const double* U,
+                        double* Q, double* speeds, void* stream);
+int cmfp_leaf_prim2cons(int fp_mode, long long n, double mass, double gamma, const double* Q,
+                        double* U, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CERBERUS_MFP_H */

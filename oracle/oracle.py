@@ -1,0 +1,159 @@
+"""ctypes front-end of the CPU oracle (oracle/libmfp_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Never imported by cerberus_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+dp = C.POINTER(C.c_double)
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libmfp_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_create.restype = C.c_void_p
+        L.orc_est_time_step.restype = C.c_double
+        L.orc_state_allowed_dt.restype = C.c_double
+        L.orc_action_allowed_dt.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---- leaves (SoA [comp][n]) -------------------------------------------------
+def reconstruct(recon, stencil):
+    stencil = _c(stencil)
+    n = stencil.shape[1]
+    slope, lo, hi = np.empty(n), np.empty(n), np.empty(n)
+    lib().orc_reconstruct(C.c_int(recon), C.c_long(n), _p(stencil), _p(slope), _p(lo), _p(hi))
+    return slope, lo, hi
+
+
+def riemann(flux, L, R, c0=0.0, ch=0.0, shock_threshold=-1.0):
+    L, R = _c(L), _c(R)
+    n = L.shape[1]
+    F = np.empty((10 if flux == 10 else 5, n))
+    lib().orc_riemann(C.c_int(flux), C.c_long(n), _p(L), _p(R), _p(F), C.c_double(c0), C.c_double(ch),
+                      C.c_double(shock_threshold))
+    return F
+
+
+def cons2prim(mass, gamma, U):
+    U = _c(U)
+    n = U.shape[1]
+    Q, s = np.empty((8, n)), np.empty((3, n))
+    lib().orc_cons2prim(C.c_long(n), C.c_double(mass), C.c_double(gamma), _p(U), _p(Q), _p(s))
+    return Q, s
+
+
+def prim2cons(mass, gamma, Q):
+    Q = _c(Q)
+    n = Q.shape[1]
+    U = np.empty((5, n))
+    lib().orc_prim2cons(C.c_long(n), C.c_double(mass), C.c_double(gamma), _p(Q), _p(U))
+    return U
+
+
+def colpiv_solve(A, b):
+    A, b = _c(A), _c(b)
+    x = np.empty_like(b)
+    lib().orc_colpiv_solve(C.c_int(len(b)), _p(A), _p(b), _p(x))
+    return x
+
+
+# ---- level ------------------------------------------------------------------
+class OracleSim:
+    """Whole-level CPU restatement driven from a cerberus_amd.config.Problem."""
+
+    def __init__(self, problem, max_grid_size=0):
+        self.p = problem
+        L = lib()
+        g, pr = problem.geometry(), problem.params()
+        sd, ad = problem.state_descs(), problem.action_descs()
+        self._keep = (g, pr, sd, ad)
+        self.h = C.c_void_p(L.orc_create(C.byref(g), C.byref(pr), C.c_int(len(problem.state_names)), sd,
+                                         C.c_int(len(problem.action_names)), ad, C.c_int(max_grid_size)))
+        self.shape = tuple(problem.n_cell[::-1])
+        for s in range(len(problem.state_names)):
+            self.set_state(s, problem.initial_data(s))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_destroy(self.h)
+            self.h = None
+
+    def set_state(self, s, data):
+        data = _c(data)
+        assert data.shape == (self.p.n_comp(s),) + self.shape, data.shape
+        lib().orc_set_state(self.h, C.c_int(s), _p(data))
+
+    def get_state(self, s):
+        out = np.empty((self.p.n_comp(s),) + self.shape)
+        lib().orc_get_state(self.h, C.c_int(s), _p(out))
+        return out
+
+    def advance(self, dt):
+        lib().orc_clear_error()
+        lib().orc_advance(self.h, C.c_double(dt))
+        if lib().orc_error_flag():
+            raise FloatingPointError("Primitive values outside of physical bounds!!")
+
+    def est_time_step(self):
+        return lib().orc_est_time_step(self.h)
+
+    def state_allowed_dt(self, s):
+        return lib().orc_state_allowed_dt(self.h, C.c_int(s))
+
+    def action_allowed_dt(self, a):
+        return lib().orc_action_allowed_dt(self.h, C.c_int(a))
+
+    def action_dU(self, a, dt, s):
+        out = np.zeros((self.p.n_comp(s),) + self.shape)
+        lib().orc_action_dU(self.h, C.c_int(a), C.c_double(dt), C.c_int(s), _p(out))
+        return out
+
+    def fill_patch(self, s):
+        ng = abi_ngrow(self.p, s)
+        shp = tuple((n + 2 * ng) if d < self.p.dim else n for d, n in enumerate(self.p.n_cell))[::-1]
+        out = np.empty((self.p.n_comp(s),) + shp)
+        lib().orc_fill_patch_global(self.h, C.c_int(s), _p(out))
+        return out
+
+    def run(self, nsteps, dt0=None):
+        """Amr::coarseTimeStep loop: computeInitialDt then computeNewDt's 1.1x
+        growth cap (MFP_timestep.cpp:23-119), no stop_time."""
+        dts = []
+        dt = self.est_time_step() if dt0 is None else dt0
+        for _ in range(nsteps):
+            self.advance(dt)
+            dts.append(dt)
+            dt = min(self.est_time_step(), 1.1 * dt)
+        return dts
+
+
+def abi_ngrow(problem, s):
+    from cerberus_amd import abi
+    name = problem.state_names[s]
+    return abi.RECON_NGROW[abi.RECON[problem.cfg["states"][name]["reconstruction"]]]
