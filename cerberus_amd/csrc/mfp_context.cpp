@@ -1,0 +1,850 @@
+// mfp_context.cpp — the C ABI of include/cerberus_mfp.h: per-GPU context,
+// HBM-resident state, the Action-API mirror and the level integrator glue
+// (MFP::advance / advance_RK / advance_strang / estTimeStep).  Host code only;
+// every kernel is reached through the cmfp::Launchers table of the selected
+// floating-point mode.  There is no CPU fallback: without a HIP device every
+// compute entry point returns CMFP_ERR_NODEVICE.
+#include "../../include/cerberus_mfp.h"
+#include "mfp_types.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+using namespace cmfp;
+
+namespace {
+
+enum Status { Inactive = 0, Local, Filled, Expired, Changed, Zero };  // UpdateData::Status, MFP_action.H:17-24
+
+int recon_num_grow(int r) {
+    switch (r) {
+    case CMFP_RECON_CONSTANT: return 1;
+    case CMFP_RECON_MINMOD:
+    case CMFP_RECON_VANLEER:
+    case CMFP_RECON_MC:
+    case CMFP_RECON_CENTRE: return 2;
+    case CMFP_RECON_O6:
+    case CMFP_RECON_WENO: return 4;
+    }
+    return -1;
+}
+
+struct StateRT {
+    cmfp_state_desc desc;
+    StatePhys sp;
+    // level data (ghosted, common geometry)
+    double* new_data = nullptr;
+    double* old_data = nullptr;
+    double* alt = nullptr;  // ping-pong partner of new_data for the fused flux kernel
+    // UpdateData
+    double* U = nullptr;
+    double* dU = nullptr;
+    Status U_status = Inactive, dU_status = Inactive;
+    // staged scratch
+    double* prim = nullptr;
+    double* rlo[3] = {nullptr, nullptr, nullptr};
+    double* rhi[3] = {nullptr, nullptr, nullptr};
+    double* flux[3] = {nullptr, nullptr, nullptr};
+};
+
+}  // namespace
+
+struct cmfp_context {
+    cmfp_geometry geom;
+    cmfp_params params;
+    Geo g;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    const Launchers* L = nullptr;
+    std::vector<StateRT> states;
+    std::vector<cmfp_action_desc> actions;
+    int nsteps = 2;
+    int fused = 1;
+    int touches[3][2];   // block face is a non-periodic physical boundary
+    int split[3];        // domain is split between ranks along d
+    cmfp_exchange_fn exchange = nullptr;
+    void* exchange_user = nullptr;
+    int* d_err = nullptr;
+    unsigned long long* d_red = nullptr;  // one reduction word per state + per action
+    std::string err;
+    std::vector<double*> allocs;
+    std::vector<double> staging;
+};
+
+namespace {
+
+int fail(cmfp_context* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(c, CMFP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+int dalloc(cmfp_context* c, double** p, long n) {
+    if (*p) return CMFP_OK;
+    HIPCHK(c, hipMalloc((void**)p, sizeof(double) * (size_t)n));
+    c->allocs.push_back(*p);
+    return CMFP_OK;
+}
+
+int ensure_update(cmfp_context* c, StateRT& s) {
+    int r;
+    if ((r = dalloc(c, &s.U, s.sp.nc * c->g.sc))) return r;
+    if ((r = dalloc(c, &s.dU, s.sp.nc * c->g.sc))) return r;
+    if ((r = dalloc(c, &s.old_data, s.sp.nc * c->g.sc))) return r;
+    return CMFP_OK;
+}
+int ensure_staged(cmfp_context* c, StateRT& s) {
+    int r;
+    if ((r = dalloc(c, &s.prim, s.sp.nq * c->g.sc))) return r;
+    for (int d = 0; d < c->g.dim; ++d) {
+        if ((r = dalloc(c, &s.rlo[d], s.sp.nq * c->g.sc))) return r;
+        if ((r = dalloc(c, &s.rhi[d], s.sp.nq * c->g.sc))) return r;
+        if ((r = dalloc(c, &s.flux[d], s.sp.nc * c->g.sc))) return r;
+    }
+    return CMFP_OK;
+}
+
+FillRules bc_rules(const StateRT& s, int d, int side) {
+    FillRules r;
+    for (int n = 0; n < 10; ++n) {
+        if (n >= s.sp.nc) {
+            r.rule[n] = FILL_SKIP;
+            continue;
+        }
+        switch (s.sp.bc[n][d][side]) {
+        case CMFP_BC_REFLECT_EVEN: r.rule[n] = FILL_EVEN; break;
+        case CMFP_BC_REFLECT_ODD: r.rule[n] = FILL_ODD; break;
+        default: r.rule[n] = FILL_FOEXTRAP; break;  // foextrap; hoextrap/ext_dir/int_dir are not produced by MFP_bc.cpp here
+        }
+    }
+    return r;
+}
+FillRules wrap_rules(const StateRT& s) {
+    FillRules r;
+    for (int n = 0; n < 10; ++n) r.rule[n] = n < s.sp.nc ? FILL_WRAP : FILL_SKIP;
+    return r;
+}
+
+// FillPatch of the new-time data, in place (MFP_action.cpp:59 -> MFP_fillbc.cpp:147-172)
+int fill_patch(cmfp_context* c, int si) {
+    StateRT& s = c->states[si];
+    const Geo& g = c->g;
+    for (int d = 0; d < g.dim; ++d) {
+        if (!c->split[d]) {
+            for (int side = 0; side < 2; ++side) {
+                FillRules r = c->geom.is_periodic[d] ? wrap_rules(s) : bc_rules(s, d, side);
+                c->L->fill_dim(g, s.sp.nc, s.sp.ng, s.new_data, d, side, r, c->stream);
+            }
+        } else {
+            for (int side = 0; side < 2; ++side)
+                if (c->touches[d][side])
+                    c->L->fill_dim(g, s.sp.nc, s.sp.ng, s.new_data, d, side, bc_rules(s, d, side), c->stream);
+            if (!c->exchange)
+                return fail(c, CMFP_ERR_INVALID, "domain is split along a dimension but no exchange callback is set");
+            int r = c->exchange(c->exchange_user, c, si, d);
+            if (r) return fail(c, CMFP_ERR_INVALID, "exchange callback failed");
+        }
+    }
+    return CMFP_OK;
+}
+
+SourceArgs source_args(cmfp_context* c, const cmfp_action_desc& A, bool on_new) {
+    SourceArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_species = A.n_states - 1;
+    for (int n = 0; n < a.n_species; ++n) {
+        StateRT& s = c->states[A.states[n]];
+        a.sp_U[n] = on_new ? s.new_data : s.U;
+        a.sp_dU[n] = s.dU;
+        a.r[n] = s.desc.charge / s.desc.mass;  // r = q / m  (MFP_plasma5.cpp:199-202)
+    }
+    StateRT& f = c->states[A.states[A.n_states - 1]];
+    a.f_U = on_new ? f.new_data : f.U;
+    a.f_dU = f.dU;
+    a.Larmor = c->params.Larmor;
+    a.Debye = c->params.Debye;
+    a.lightspeed = c->params.lightspeed;
+    a.c_h = f.sp.fp.ch;
+    a.div_damp = f.desc.div_damping;
+    a.lorentz_only = A.kind == CMFP_ACTION_LORENTZ;
+    a.implicit = (A.kind == CMFP_ACTION_PLASMA5 && A.solver == CMFP_SOLVER_IMPLICIT);
+    return a;
+}
+
+// Action::get_data MFP_action.cpp:15-102 for one (state, fill) option
+int get_data_one(cmfp_context* c, int si, bool fill) {
+    StateRT& s = c->states[si];
+    const Geo& g = c->g;
+    int r;
+    if ((r = ensure_update(c, s))) return r;
+    if (fill) {
+        if (s.U_status != Filled) {
+            if ((r = fill_patch(c, si))) return r;
+            c->L->copy(g, s.sp.nc, s.U, s.new_data, 1, c->stream);
+            s.U_status = Filled;
+        }
+    } else {
+        if (s.U_status != Local && s.U_status != Filled) {
+            c->L->copy(g, s.sp.nc, s.U, s.new_data, 0, c->stream);
+            s.U_status = Local;
+        }
+    }
+    if (s.dU_status == Expired || s.dU_status == Inactive) {
+        c->L->zero(g, s.sp.nc, s.dU, c->stream);
+        s.dU_status = Zero;
+    }
+    return CMFP_OK;
+}
+
+int action_get_data(cmfp_context* c, int ai) {
+    const cmfp_action_desc& A = c->actions[ai];
+    int r;
+    if (A.kind == CMFP_ACTION_CTU) {  // HydroCTU::get_data MFP_CTU_hydro.cpp:43-52
+        for (int i = 0; i < A.n_states; ++i)
+            if ((r = get_data_one(c, A.states[i], true))) return r;
+    } else {  // Plasma5::get_data MFP_plasma5.cpp:60-71, Lorentz::get_data MFP_lorentz.cpp:47-58
+        if ((r = get_data_one(c, A.states[A.n_states - 1], false))) return r;
+        for (int i = 0; i < A.n_states - 1; ++i)
+            if ((r = get_data_one(c, A.states[i], false))) return r;
+    }
+    return CMFP_OK;
+}
+
+int action_calc_time_derivative(cmfp_context* c, int ai, double dt) {
+    const cmfp_action_desc& A = c->actions[ai];
+    if (A.kind == CMFP_ACTION_CTU) return CMFP_OK;  // Action::calc_time_derivative default (MFP_action.H:67-70)
+    SourceArgs a = source_args(c, A, false);
+    for (int n = 0; n < A.n_states - 1; ++n) c->states[A.states[n]].dU_status = Changed;
+    if (A.kind == CMFP_ACTION_PLASMA5) c->states[A.states[A.n_states - 1]].dU_status = Changed;  // MFP_plasma5.cpp:96,255
+    c->L->source(c->g, a, dt, c->stream);
+    return CMFP_OK;
+}
+
+// HydroCTU::calc_spatial_derivative MFP_CTU_hydro.cpp:54-532, one kernel per stage
+int ctu_staged(cmfp_context* c, const cmfp_action_desc& A, double dt) {
+    const Geo& g = c->g;
+    const int do_ctu = A.corner_transport != 0;
+    for (int idx = 0; idx < A.n_states; ++idx) {
+        StateRT& s = c->states[A.states[idx]];
+        int r;
+        if ((r = ensure_staged(c, s))) return r;
+        s.dU_status = Changed;  // :88
+        Ptr3 rlo{{s.rlo[0], s.rlo[1], s.rlo[2]}}, rhi{{s.rhi[0], s.rhi[1], s.rhi[2]}};
+        Ptr3 fl{{s.flux[0], s.flux[1], s.flux[2]}};
+        c->L->prim(g, s.sp, s.U, s.prim, c->d_err, c->stream);                       // :182
+        c->L->recon(g, s.sp, s.prim, rlo, rhi, do_ctu, dt, c->stream);               // :212,230
+        for (int d = 0; d < g.dim; ++d)                                              // :297
+            c->L->fluxes(g, s.sp, d, s.rlo[d], s.rhi[d], s.flux[d], do_ctu, c->stream);
+        if (g.dim > 1 && do_ctu) {
+            for (int d1 = 0; d1 < g.dim; ++d1)                                       // :316
+                c->L->correct(g, s.sp, d1, s.rlo[d1], s.rhi[d1], fl, dt, c->d_err, c->stream);
+            for (int d = 0; d < g.dim; ++d)                                          // :328
+                for (int side = 0; side < 2; ++side)
+                    if (c->touches[d][side]) c->L->face_bc(g, s.sp, d, side, s.rlo[d], s.rhi[d], c->stream);
+            for (int d = 0; d < g.dim; ++d)                                          // :349
+                c->L->fluxes(g, s.sp, d, s.rlo[d], s.rhi[d], s.flux[d], do_ctu, c->stream);
+        }
+        c->L->divergence(g, s.sp.nc, fl, s.dU, dt, c->stream);                       // :504
+    }
+    return CMFP_OK;
+}
+
+int action_calc_spatial_derivative(cmfp_context* c, int ai, double dt) {
+    const cmfp_action_desc& A = c->actions[ai];
+    if (A.kind != CMFP_ACTION_CTU) return CMFP_OK;
+    return ctu_staged(c, A, dt);
+}
+
+void swap_levels(cmfp_context* c) {
+    // state[i].swapTimeLevels + copy old into new (MFP_advance.cpp:10-25): old := new
+    for (auto& s : c->states)
+        if (s.old_data) c->L->copy(c->g, s.sp.nc, s.old_data, s.new_data, 0, c->stream);
+}
+
+// MFP::advance_RK MFP_advance.cpp:58-135
+int advance_RK(cmfp_context* c, double dt) {
+    const Geo& g = c->g;
+    int r;
+    for (auto& s : c->states) s.U_status = s.dU_status = Inactive;
+    for (size_t a = 0; a < c->actions.size(); ++a) {
+        if ((r = action_get_data(c, (int)a))) return r;
+        if ((r = action_calc_time_derivative(c, (int)a, dt))) return r;
+        if ((r = action_calc_spatial_derivative(c, (int)a, dt))) return r;
+    }
+    for (auto& s : c->states) {
+        if (s.dU_status != Changed) continue;
+        c->L->add(g, s.sp.nc, s.new_data, s.dU, c->stream);
+        s.U_status = Expired;
+        s.dU_status = Expired;
+    }
+    if (c->nsteps >= 2) {
+        for (size_t a = 0; a < c->actions.size(); ++a) {
+            if ((r = action_get_data(c, (int)a))) return r;
+            if ((r = action_calc_time_derivative(c, (int)a, dt))) return r;
+            if ((r = action_calc_spatial_derivative(c, (int)a, dt))) return r;
+        }
+        for (auto& s : c->states) {
+            if (s.dU_status != Changed) continue;
+            c->L->add(g, s.sp.nc, s.U, s.dU, c->stream);
+            c->L->lincomb(g, s.sp.nc, s.new_data, 0.5, s.old_data, 0.5, s.U, c->stream);
+        }
+    }
+    return CMFP_OK;
+}
+
+// MFP::advance_strang MFP_advance.cpp:137-289
+int advance_strang(cmfp_context* c, double dt) {
+    const Geo& g = c->g;
+    int r;
+    for (auto& s : c->states) s.U_status = s.dU_status = Inactive;
+    const int na = (int)c->actions.size();
+
+    for (int a = 0; a < na; ++a) {
+        if ((r = action_get_data(c, a))) return r;
+        if ((r = action_calc_time_derivative(c, a, 0.5 * dt))) return r;
+    }
+    for (auto& s : c->states) {
+        if (s.dU_status != Changed) continue;
+        if (c->nsteps >= 2) {
+            c->L->add(g, s.sp.nc, s.U, s.dU, c->stream);
+            c->L->zero(g, s.sp.nc, s.dU, c->stream);
+            s.dU_status = Expired;
+        } else {
+            c->L->add(g, s.sp.nc, s.new_data, s.dU, c->stream);
+        }
+    }
+    if (c->nsteps >= 2) {
+        for (int a = 0; a < na; ++a)
+            if ((r = action_calc_time_derivative(c, a, 0.5 * dt))) return r;
+        for (auto& s : c->states) {
+            if (s.dU_status != Changed) continue;
+            c->L->add(g, s.sp.nc, s.U, s.dU, c->stream);
+            c->L->zero(g, s.sp.nc, s.dU, c->stream);
+            c->L->lincomb(g, s.sp.nc, s.new_data, 0.5, s.old_data, 0.5, s.U, c->stream);
+            s.U_status = Expired;
+            s.dU_status = Expired;
+        }
+    }
+
+    for (int a = 0; a < na; ++a) {
+        if ((r = action_get_data(c, a))) return r;
+        if ((r = action_calc_spatial_derivative(c, a, dt))) return r;
+    }
+    for (auto& s : c->states) {
+        if (s.dU_status != Changed) continue;
+        c->L->add(g, s.sp.nc, s.new_data, s.dU, c->stream);
+        s.U_status = Expired;
+        s.dU_status = Expired;
+    }
+
+    for (int a = 0; a < na; ++a) {
+        if ((r = action_get_data(c, a))) return r;
+        if ((r = action_calc_time_derivative(c, a, 0.5 * dt))) return r;
+    }
+    for (auto& s : c->states) {
+        if (s.dU_status != Changed) continue;
+        if (c->nsteps >= 2) {
+            c->L->add(g, s.sp.nc, s.U, s.dU, c->stream);
+            c->L->zero(g, s.sp.nc, s.dU, c->stream);
+            s.dU_status = Inactive;
+        } else {
+            c->L->add(g, s.sp.nc, s.new_data, s.dU, c->stream);
+        }
+    }
+    if (c->nsteps >= 2) {
+        for (int a = 0; a < na; ++a)
+            if ((r = action_calc_time_derivative(c, a, 0.5 * dt))) return r;
+        for (auto& s : c->states) {
+            if (s.dU_status != Changed) continue;
+            c->L->add(g, s.sp.nc, s.U, s.dU, c->stream);
+            c->L->zero(g, s.sp.nc, s.dU, c->stream);
+            c->L->lincomb(g, s.sp.nc, s.new_data, 0.5, s.new_data, 0.5, s.U, c->stream);
+        }
+    }
+    return CMFP_OK;
+}
+
+// The same Strang step through the hand-fused kernels: one pointwise RK2
+// source kernel per half step (in place on the new-time data), ghost fill in
+// place, one fused CTU kernel per state writing new + dU into the ping-pong
+// partner.  Returns 1 if it ran, 0 if the configuration is outside what the
+// fused kernels cover (caller then takes the staged path), <0 on error.
+int advance_strang_fused(cmfp_context* c, double dt) {
+    if (c->params.time_integrator != CMFP_TI_STRANG) return 0;
+    int n_src = 0, src = -1;
+    std::vector<int> seen(c->states.size(), 0);
+    for (size_t a = 0; a < c->actions.size(); ++a) {
+        const cmfp_action_desc& A = c->actions[a];
+        if (A.kind == CMFP_ACTION_CTU) {
+            for (int i = 0; i < A.n_states; ++i)
+                if (seen[A.states[i]]++) return 0;
+        } else {
+            ++n_src;
+            src = (int)a;
+            if (A.n_states - 1 > 4) return 0;
+        }
+    }
+    if (n_src > 1) return 0;
+    // probe coverage of the fused CTU kernel (null launch)
+    for (const auto& A : c->actions)
+        if (A.kind == CMFP_ACTION_CTU)
+            for (int i = 0; i < A.n_states; ++i)
+                if (!c->L->ctu_fused(c->g, c->states[A.states[i]].sp, nullptr, nullptr, A.corner_transport, dt, c->touches,
+                                     nullptr, c->stream))
+                    return 0;
+    if (src >= 0) {
+        SourceArgs a = source_args(c, c->actions[src], true);
+        if (!c->L->source_fused(c->g, a, 0.5 * dt, c->stream)) return 0;
+    }
+    for (const auto& A : c->actions) {
+        if (A.kind != CMFP_ACTION_CTU) continue;
+        for (int i = 0; i < A.n_states; ++i) {
+            StateRT& s = c->states[A.states[i]];
+            int r;
+            if ((r = dalloc(c, &s.alt, s.sp.nc * c->g.sc))) return r;
+            if ((r = fill_patch(c, A.states[i]))) return r;
+            c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, A.corner_transport, dt, c->touches, c->d_err, c->stream);
+            std::swap(s.new_data, s.alt);
+        }
+    }
+    if (src >= 0) {
+        SourceArgs a = source_args(c, c->actions[src], true);
+        c->L->source_fused(c->g, a, 0.5 * dt, c->stream);
+    }
+    return 1;
+}
+
+int check_ctx(cmfp_context* c) {
+    if (!c) return CMFP_ERR_INVALID;
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, CMFP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return CMFP_OK;
+}
+
+int sync_and_check(cmfp_context* c) {
+    int h_err = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_err) return fail(c, CMFP_ERR_PHYSICS, "Primitive values outside of physical bounds!!");
+    return CMFP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cmfp_version(void) { return "cerberus_mfp 0.1 (gfx950, strict+fast)"; }
+
+int cmfp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_states, const cmfp_state_desc* states,
+                int n_actions, const cmfp_action_desc* actions, int device, void* stream, cmfp_context** out) {
+    if (!geom || !params || !states || !out || n_states < 1) return CMFP_ERR_INVALID;
+    if (geom->dim < 1 || geom->dim > 3) return CMFP_ERR_INVALID;
+    if (cmfp_device_count() <= device) return CMFP_ERR_NODEVICE;
+    cmfp_context* c = new cmfp_context();
+    *out = c;  // returned even on failure so that cmfp_last_error can be read; caller destroys it
+    c->geom = *geom;
+    c->params = *params;
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    c->L = params->fp_mode == CMFP_FP_FAST ? fast::launchers() : strict::launchers();
+    c->nsteps = params->time_integrator == CMFP_TI_EULER ? 1 : 2;  // MFP_config.cpp:73-81
+    HIPCHK(c, hipSetDevice(device));
+
+    int ng = 0;
+    for (int s = 0; s < n_states; ++s) {
+        int n = recon_num_grow(states[s].reconstruction);
+        if (n < 0) return fail(c, CMFP_ERR_INVALID, "unknown reconstruction");
+        ng = std::max(ng, n);
+    }
+    Geo& g = c->g;
+    g.dim = geom->dim;
+    for (int d = 0; d < 3; ++d) {
+        const bool on = d < geom->dim;
+        g.n[d] = on ? geom->block_n[d] : 1;
+        g.ng[d] = on ? ng : 0;
+        g.ext[d] = g.n[d] + 2 * g.ng[d];
+        g.dx[d] = on ? geom->dx[d] : 1.0;
+        if (on && (geom->block_n[d] < ng || geom->block_lo[d] < 0 || geom->block_lo[d] + geom->block_n[d] > geom->n_cell[d]))
+            return fail(c, CMFP_ERR_INVALID, "block does not fit the domain or is thinner than the ghost width");
+        c->split[d] = on && geom->block_n[d] != geom->n_cell[d];
+        c->touches[d][0] = on && !geom->is_periodic[d] && geom->block_lo[d] == 0;
+        c->touches[d][1] = on && !geom->is_periodic[d] && geom->block_lo[d] + geom->block_n[d] == geom->n_cell[d];
+    }
+    g.sj = g.ext[0];
+    g.sk = (long)g.ext[0] * g.ext[1];
+    g.sc = g.sk * g.ext[2];
+
+    c->states.resize(n_states);
+    for (int s = 0; s < n_states; ++s) {
+        StateRT& st = c->states[s];
+        st.desc = states[s];
+        StatePhys& sp = st.sp;
+        std::memset(&sp, 0, sizeof(sp));
+        sp.kind = states[s].kind;
+        sp.recon = states[s].reconstruction;
+        sp.flux = states[s].flux;
+        sp.ng = recon_num_grow(sp.recon);
+        if (sp.kind == CMFP_STATE_HYDRO) {
+            sp.nc = sp.nq = 5;
+            if (sp.flux != CMFP_FLUX_HLLC && sp.flux != CMFP_FLUX_HLLE && sp.flux != CMFP_FLUX_HYBRID_HLL)
+                return fail(c, CMFP_ERR_INVALID, "hydro flux must be HLLC, HLLE or HLLE/HLLC");
+            if (!(states[s].mass != 0.0) || !(states[s].gamma != 0.0) || states[s].gamma == 1.0)
+                return fail(c, CMFP_ERR_INVALID, "mass and gamma cannot be 0");  // MFP_thermally_perfect_gas.cpp:29-30
+            sp.hp.gas = GasP{states[s].mass, states[s].charge, states[s].gamma};
+            sp.hp.shock_threshold = states[s].shock_threshold;
+        } else if (sp.kind == CMFP_STATE_FIELD) {
+            sp.nc = sp.nq = 10;
+            if (sp.flux != CMFP_FLUX_FIELD_RH) return fail(c, CMFP_ERR_INVALID, "field flux must be RankineHugoniot");
+            sp.fp.c0 = params->lightspeed;
+            sp.fp.ch = states[s].div_transport * params->lightspeed;  // MFP_field.cpp:382-386
+            sp.fp.fastest = std::max(params->lightspeed, sp.fp.ch);
+        } else {
+            return fail(c, CMFP_ERR_INVALID, "unknown state kind");
+        }
+        std::memcpy(sp.bc, states[s].bc, sizeof(sp.bc));
+        int r;
+        if ((r = dalloc(c, &st.new_data, sp.nc * g.sc))) return r;
+        HIPCHK(c, hipMemsetAsync(st.new_data, 0, sizeof(double) * sp.nc * g.sc, c->stream));
+    }
+    c->actions.assign(actions, actions + n_actions);
+    for (const auto& A : c->actions) {
+        if (A.n_states < 1 || A.n_states > CMFP_MAX_ACTION_STATES) return fail(c, CMFP_ERR_INVALID, "bad action state count");
+        for (int i = 0; i < A.n_states; ++i)
+            if (A.states[i] < 0 || A.states[i] >= n_states) return fail(c, CMFP_ERR_INVALID, "bad action state index");
+        if (A.kind == CMFP_ACTION_CTU) continue;
+        if (A.kind != CMFP_ACTION_PLASMA5 && A.kind != CMFP_ACTION_LORENTZ) return fail(c, CMFP_ERR_INVALID, "unknown action kind");
+        if (A.n_states - 1 > 4) return fail(c, CMFP_ERR_INVALID, "at most 4 species per source action");
+        if (c->states[A.states[A.n_states - 1]].sp.kind != CMFP_STATE_FIELD)
+            return fail(c, CMFP_ERR_INVALID, "source action: last state must be the field");
+        for (int i = 0; i < A.n_states - 1; ++i)
+            if (c->states[A.states[i]].sp.kind != CMFP_STATE_HYDRO)
+                return fail(c, CMFP_ERR_INVALID, "source action: species must be hydro states");
+    }
+    HIPCHK(c, hipMalloc((void**)&c->d_err, sizeof(int)));
+    HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMalloc((void**)&c->d_red, sizeof(unsigned long long) * (n_states + n_actions + 1)));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CMFP_OK;
+}
+
+int cmfp_destroy(cmfp_context* c) {
+    if (!c) return CMFP_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (double* p : c->allocs) (void)hipFree(p);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_red) (void)hipFree(c->d_red);
+    delete c;
+    return CMFP_OK;
+}
+
+const char* cmfp_last_error(const cmfp_context* c) { return c ? c->err.c_str() : "null context"; }
+
+int cmfp_state_ncomp(const cmfp_context* c, int s) {
+    return (c && s >= 0 && s < (int)c->states.size()) ? c->states[s].sp.nc : CMFP_ERR_INVALID;
+}
+int cmfp_state_ngrow(const cmfp_context* c, int s) {
+    return (c && s >= 0 && s < (int)c->states.size()) ? c->states[s].sp.ng : CMFP_ERR_INVALID;
+}
+
+static int copy_state(cmfp_context* c, double* dev, int nc, double* host, bool upload) {
+    const Geo& g = c->g;
+    c->staging.resize((size_t)nc * g.sc);
+    double* stg = c->staging.data();
+    const size_t bytes = sizeof(double) * (size_t)nc * g.sc;
+    if (!upload) {
+        HIPCHK(c, hipMemcpyAsync(stg, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        std::fill(c->staging.begin(), c->staging.end(), 0.0);
+    }
+    for (int n = 0; n < nc; ++n)
+        for (int k = 0; k < g.n[2]; ++k)
+            for (int j = 0; j < g.n[1]; ++j) {
+                double* d = stg + g.at(0, j, k) + (size_t)n * g.sc;
+                double* h = host + (((size_t)n * g.n[2] + k) * g.n[1] + j) * g.n[0];
+                if (upload)
+                    std::memcpy(d, h, sizeof(double) * g.n[0]);
+                else
+                    std::memcpy(h, d, sizeof(double) * g.n[0]);
+            }
+    if (upload) {
+        HIPCHK(c, hipMemcpyAsync(dev, stg, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    std::vector<double>().swap(c->staging);
+    return CMFP_OK;
+}
+
+int cmfp_state_upload(cmfp_context* c, int s, const double* host) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (s < 0 || s >= (int)c->states.size() || !host) return fail(c, CMFP_ERR_INVALID, "bad state index / pointer");
+    return copy_state(c, c->states[s].new_data, c->states[s].sp.nc, const_cast<double*>(host), true);
+}
+int cmfp_state_download(cmfp_context* c, int s, double* host) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (s < 0 || s >= (int)c->states.size() || !host) return fail(c, CMFP_ERR_INVALID, "bad state index / pointer");
+    if ((r = sync_and_check(c))) return r;
+    return copy_state(c, c->states[s].new_data, c->states[s].sp.nc, host, false);
+}
+int cmfp_state_device_view(cmfp_context* c, int s, double** dptr, int* ngrow, long long extent[CMFP_MAX_DIM], int* ncomp) {
+    if (!c || s < 0 || s >= (int)c->states.size()) return CMFP_ERR_INVALID;
+    if (dptr) *dptr = c->states[s].new_data;
+    if (ngrow) *ngrow = c->g.ng[0];
+    if (extent)
+        for (int d = 0; d < 3; ++d) extent[d] = c->g.ext[d];
+    if (ncomp) *ncomp = c->states[s].sp.nc;
+    return CMFP_OK;
+}
+
+int cmfp_update_begin(cmfp_context* c) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    for (auto& s : c->states) {
+        s.U_status = s.dU_status = Inactive;
+        if ((r = ensure_update(c, s))) return r;
+    }
+    swap_levels(c);
+    return CMFP_OK;
+}
+int cmfp_action_get_data(cmfp_context* c, int a, double) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (a < 0 || a >= (int)c->actions.size()) return fail(c, CMFP_ERR_INVALID, "bad action index");
+    return action_get_data(c, a);
+}
+int cmfp_action_calc_time_derivative(cmfp_context* c, int a, double, double dt) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (a < 0 || a >= (int)c->actions.size()) return fail(c, CMFP_ERR_INVALID, "bad action index");
+    return action_calc_time_derivative(c, a, dt);
+}
+int cmfp_action_calc_spatial_derivative(cmfp_context* c, int a, double, double dt, double) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (a < 0 || a >= (int)c->actions.size()) return fail(c, CMFP_ERR_INVALID, "bad action index");
+    return action_calc_spatial_derivative(c, a, dt);
+}
+
+int cmfp_update_download(cmfp_context* c, int s, int which, double* host) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (s < 0 || s >= (int)c->states.size() || !host) return fail(c, CMFP_ERR_INVALID, "bad state index / pointer");
+    double* p = which == 0 ? c->states[s].U : c->states[s].dU;
+    if (!p) return fail(c, CMFP_ERR_INVALID, "UpdateData not defined for this state");
+    if ((r = sync_and_check(c))) return r;
+    return copy_state(c, p, c->states[s].sp.nc, host, false);
+}
+
+static int reduce_words(cmfp_context* c, std::vector<unsigned long long>& h) {
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->d_red, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    int r;
+    if ((r = sync_and_check(c))) return r;
+    return CMFP_OK;
+}
+static double as_double(unsigned long long b) {
+    double d;
+    std::memcpy(&d, &b, sizeof(d));
+    return d;
+}
+
+// launches the reduction for state s into word w; hydro only
+static int launch_state_dt(cmfp_context* c, int s, int w) {
+    HIPCHK(c, hipMemsetAsync(c->d_red + w, 0, sizeof(unsigned long long), c->stream));
+    c->L->max_speed(c->g, c->states[s].sp, c->states[s].new_data, c->d_red + w, c->stream);
+    return CMFP_OK;
+}
+static double state_dt_from(const cmfp_context* c, int s, double max_speed) {
+    const StateRT& st = c->states[s];
+    const Geo& g = c->g;
+    const double sp = st.sp.kind == CMFP_STATE_HYDRO ? max_speed : st.sp.fp.fastest;
+    double dt = g.dx[0] / sp;  // MFP_eulerian.cpp:302-303, MFP_field.cpp:63-64
+    for (int i = 1; i < g.dim; ++i) dt = std::min(dt, g.dx[i] / sp);
+    return dt;
+}
+static int launch_action_dt(cmfp_context* c, int a, int w) {
+    // 0x7f7f...7f is a positive double (~1.4e306) above any time step: the identity of the min
+    HIPCHK(c, hipMemsetAsync(c->d_red + w, 0x7f, sizeof(unsigned long long), c->stream));
+    SourceArgs sa = source_args(c, c->actions[a], true);
+    c->L->plasma_dt(c->g, sa, c->d_red + w, c->stream);
+    return CMFP_OK;
+}
+static bool action_limits_dt(const cmfp_action_desc& A) {
+    return A.kind == CMFP_ACTION_PLASMA5 && A.solver == CMFP_SOLVER_EXPLICIT;  // MFP_plasma5.cpp:461
+}
+static double action_dt_from(const cmfp_context* c, int a, double cell_min) {
+    const cmfp_action_desc& A = c->actions[a];
+    const Geo& g = c->g;
+    const StateRT& f = c->states[A.states[A.n_states - 1]];
+    double max_speed = c->params.lightspeed;  // MFP_plasma5.cpp:494-498
+    max_speed = std::max(max_speed, f.sp.fp.ch);
+    double dt = g.dx[0] / max_speed;
+    for (int d = 1; d < g.dim; ++d) dt = std::min(dt, g.dx[d] / max_speed);
+    return std::min(dt, cell_min);
+}
+
+int cmfp_state_get_allowed_time_step(cmfp_context* c, int s, double* dt) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (s < 0 || s >= (int)c->states.size() || !dt) return fail(c, CMFP_ERR_INVALID, "bad state index / pointer");
+    std::vector<unsigned long long> h(1, 0);
+    if (c->states[s].sp.kind == CMFP_STATE_HYDRO) {
+        if ((r = launch_state_dt(c, s, 0))) return r;
+        if ((r = reduce_words(c, h))) return r;
+    }
+    *dt = state_dt_from(c, s, as_double(h[0]));
+    return CMFP_OK;
+}
+int cmfp_action_get_allowed_time_step(cmfp_context* c, int a, double* dt) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (a < 0 || a >= (int)c->actions.size() || !dt) return fail(c, CMFP_ERR_INVALID, "bad action index / pointer");
+    if (!action_limits_dt(c->actions[a])) {
+        *dt = std::numeric_limits<double>::max();  // MFP_action.H:87, MFP_plasma5.cpp:461
+        return CMFP_OK;
+    }
+    std::vector<unsigned long long> h(1, 0);
+    if ((r = launch_action_dt(c, a, 0))) return r;
+    if ((r = reduce_words(c, h))) return r;
+    *dt = action_dt_from(c, a, as_double(h[0]));
+    return CMFP_OK;
+}
+
+// MFP::estTimeStep MFP_timestep.cpp:4-21 without the cross-rank ReduceRealMin
+int cmfp_est_time_step(cmfp_context* c, double* out) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (!out) return fail(c, CMFP_ERR_INVALID, "null pointer");
+    const int ns = (int)c->states.size(), na = (int)c->actions.size();
+    std::vector<unsigned long long> h(ns + na, 0);
+    for (int s = 0; s < ns; ++s)
+        if (c->states[s].sp.kind == CMFP_STATE_HYDRO)
+            if ((r = launch_state_dt(c, s, s))) return r;
+    for (int a = 0; a < na; ++a)
+        if (action_limits_dt(c->actions[a]))
+            if ((r = launch_action_dt(c, a, ns + a))) return r;
+    if ((r = reduce_words(c, h))) return r;
+    double estdt = std::numeric_limits<double>::max();
+    for (int s = 0; s < ns; ++s) estdt = std::min(estdt, state_dt_from(c, s, as_double(h[s])));
+    for (int a = 0; a < na; ++a)
+        if (action_limits_dt(c->actions[a])) estdt = std::min(estdt, action_dt_from(c, a, as_double(h[ns + a])));
+    estdt *= c->params.cfl;
+    *out = estdt;
+    return CMFP_OK;
+}
+
+double cmfp_compute_new_dt(double est_dt, double old_dt) {
+    const double change_max = 1.1;  // MFP_timestep.cpp:89-92
+    return std::min(est_dt, change_max * old_dt);
+}
+
+int cmfp_set_fused(cmfp_context* c, int enable) {
+    if (!c) return CMFP_ERR_INVALID;
+    c->fused = enable;
+    return CMFP_OK;
+}
+
+// MFP::advance MFP_advance.cpp:6-56
+int cmfp_advance(cmfp_context* c, double, double dt) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (c->fused) {
+        r = advance_strang_fused(c, dt);
+        if (r < 0) return r;
+        if (r == 1) return CMFP_OK;
+    }
+    for (auto& s : c->states)
+        if ((r = ensure_update(c, s))) return r;
+    swap_levels(c);
+    if (c->params.time_integrator == CMFP_TI_STRANG) return advance_strang(c, dt);
+    return advance_RK(c, dt);
+}
+
+int cmfp_set_exchange_callback(cmfp_context* c, cmfp_exchange_fn fn, void* user) {
+    if (!c) return CMFP_ERR_INVALID;
+    c->exchange = fn;
+    c->exchange_user = user;
+    return CMFP_OK;
+}
+int cmfp_fill_patch(cmfp_context* c, int s) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (s < 0 || s >= (int)c->states.size()) return fail(c, CMFP_ERR_INVALID, "bad state index");
+    return fill_patch(c, s);
+}
+long long cmfp_halo_count(const cmfp_context* c, int s, int dim) {
+    if (!c || s < 0 || s >= (int)c->states.size() || dim < 0 || dim >= c->g.dim) return CMFP_ERR_INVALID;
+    long long n = (long long)c->states[s].sp.nc * c->states[s].sp.ng;
+    for (int t = 0; t < 3; ++t)
+        if (t != dim) n *= c->g.ext[t];
+    return n;
+}
+int cmfp_halo_pack(cmfp_context* c, int s, int dim, int side, double* dbuf) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (s < 0 || s >= (int)c->states.size() || dim < 0 || dim >= c->g.dim || !dbuf)
+        return fail(c, CMFP_ERR_INVALID, "bad halo arguments");
+    StateRT& st = c->states[s];
+    c->L->pack(c->g, st.sp.nc, st.sp.ng, st.new_data, dim, side, dbuf, 0, c->stream);
+    return CMFP_OK;
+}
+int cmfp_halo_unpack(cmfp_context* c, int s, int dim, int side, const double* dbuf) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (s < 0 || s >= (int)c->states.size() || dim < 0 || dim >= c->g.dim || !dbuf)
+        return fail(c, CMFP_ERR_INVALID, "bad halo arguments");
+    StateRT& st = c->states[s];
+    c->L->pack(c->g, st.sp.nc, st.sp.ng, st.new_data, dim, side, const_cast<double*>(dbuf), 1, c->stream);
+    return CMFP_OK;
+}
+
+static const Launchers* mode(int fp_mode) { return fp_mode == CMFP_FP_FAST ? fast::launchers() : strict::launchers(); }
+
+int cmfp_leaf_reconstruct(int recon, int fp_mode, long long n, const double* stencil, double* slope, double* lo,
+                          double* hi, void* stream) {
+    if (cmfp_device_count() < 1) return CMFP_ERR_NODEVICE;
+    if (n <= 0 || !stencil || !slope || !lo || !hi) return CMFP_ERR_INVALID;
+    return mode(fp_mode)->leaf_reconstruct(recon, (long)n, stencil, slope, lo, hi, (hipStream_t)stream) ? CMFP_OK
+                                                                                                        : CMFP_ERR_INVALID;
+}
+int cmfp_leaf_riemann(int flux, int fp_mode, long long n, const double* L, const double* R, double* F, double c0,
+                      double ch, double shock_threshold, void* stream) {
+    if (cmfp_device_count() < 1) return CMFP_ERR_NODEVICE;
+    if (n <= 0 || !L || !R || !F) return CMFP_ERR_INVALID;
+    return mode(fp_mode)->leaf_riemann(flux, (long)n, L, R, F, c0, ch, shock_threshold, (hipStream_t)stream) ? CMFP_OK
+                                                                                                              : CMFP_ERR_INVALID;
+}
+int cmfp_leaf_cons2prim(int fp_mode, long long n, double mass, double gamma, const double* U, double* Q, double* speeds,
+                        void* stream) {
+    if (cmfp_device_count() < 1) return CMFP_ERR_NODEVICE;
+    if (n <= 0 || !U || !Q || !speeds) return CMFP_ERR_INVALID;
+    return mode(fp_mode)->leaf_cons2prim((long)n, mass, gamma, U, Q, speeds, (hipStream_t)stream) ? CMFP_OK : CMFP_ERR_INVALID;
+}
+int cmfp_leaf_prim2cons(int fp_mode, long long n, double mass, double gamma, const double* Q, double* U, void* stream) {
+    if (cmfp_device_count() < 1) return CMFP_ERR_NODEVICE;
+    if (n <= 0 || !Q || !U) return CMFP_ERR_INVALID;
+    return mode(fp_mode)->leaf_prim2cons((long)n, mass, gamma, Q, U, (hipStream_t)stream) ? CMFP_OK : CMFP_ERR_INVALID;
+}
+
+}  // extern "C"

@@ -1,0 +1,909 @@
+// mfp_kernels.hip — stage-by-stage HIP kernels (gfx950) of the hyperbolic
+// update, one per FAB-level function of the reference, plus sources, dt
+// reductions, ghost fill / halo pack and the batched leaf kernels.
+//
+// Compiled twice: -DCMFP_NS=strict -ffp-contract=off and -DCMFP_NS=fast
+// -ffp-contract=fast.  All arrays are fp64 SoA (i fastest, component slowest)
+// with the state's ghost width on every array, so one thread per cell gives
+// fully coalesced 8-byte lane accesses on every component plane.
+#include "mfp_device.h"
+
+#include <cfloat>
+
+namespace CMFP_NS {
+
+using namespace cmfp;
+
+static constexpr int TPB = 256;
+static inline unsigned nblocks(long n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+__device__ __forceinline__ bool decode(const IBox& b, long t, int& i, int& j, int& k) {
+    const int l0 = b.hi[0] - b.lo[0] + 1, l1 = b.hi[1] - b.lo[1] + 1, l2 = b.hi[2] - b.lo[2] + 1;
+    if (t >= (long)l0 * l1 * l2) return false;
+    i = b.lo[0] + (int)(t % l0);
+    t /= l0;
+    j = b.lo[1] + (int)(t % l1);
+    k = b.lo[2] + (int)(t / l1);
+    return true;
+}
+
+static IBox valid_box(const Geo& g) {
+    IBox b;
+    for (int d = 0; d < 3; ++d) {
+        b.lo[d] = 0;
+        b.hi[d] = g.n[d] - 1;
+    }
+    return b;
+}
+static IBox grown_box(const Geo& g, int n) {
+    IBox b = valid_box(g);
+    for (int d = 0; d < g.dim; ++d) {
+        b.lo[d] -= n;
+        b.hi[d] += n;
+    }
+    return b;
+}
+
+// ------------------------------------------------------------ calc_primitives
+// EulerianState::calc_primitives MFP_eulerian.cpp:313-433 over grow(box, num_grow).
+template <bool HYDRO>
+__global__ void k_prim(Geo g, IBox box, HydroParams hp, const double* __restrict__ U, double* __restrict__ Q, int* err) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long t = g.at(i, j, k);
+    if (HYDRO) {
+        double u[5], q[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) u[n] = U[t + n * g.sc];
+        if (!hydro_cons2prim(hp.gas, u, q)) *err = 1;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) Q[t + n * g.sc] = q[n];
+    } else {
+#pragma unroll
+        for (int n = 0; n < 10; ++n) Q[t + n * g.sc] = U[t + n * g.sc];
+    }
+}
+
+// ------------------------------------------ calc_reconstruction + time average
+// HydroState::calc_reconstruction MFP_hydro.cpp:780-1038 /
+// EulerianState::calc_reconstruction MFP_eulerian.cpp:513-607, then (do_ctu)
+// EulerianState::calc_time_averaged_faces MFP_eulerian.cpp:609-676, on grow(box,1).
+template <bool HYDRO, int RECON>
+__global__ void k_recon(Geo g, IBox box, HydroParams hp, FieldParams fp, const double* __restrict__ Q, Ptr3 rlo,
+                        Ptr3 rhi, int do_ctu, double dt) {
+    constexpr int SL = ReconTraits<RECON>::SL;
+    constexpr int off = SL / 2;
+    constexpr int NQ = HYDRO ? 5 : 10;
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long c0 = g.at(i, j, k);
+    const long str[3] = {1, g.sj, g.sk};
+
+    double centre[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) centre[n] = Q[c0 + n * g.sc];
+    double speed[3];
+    if (HYDRO) {
+        // the reference stores eps = p/(gamma-1) in place during reconstruction and
+        // restores p = eps*(gamma-1) afterwards (MFP_hydro.cpp:847-862,1025-1035):
+        // the time-average step sees that round-tripped pressure
+        const double gm1 = hp.gas.gamma - 1.0;
+        centre[H_P] = (centre[H_P] / gm1) * gm1;
+        hydro_speed_from_prim(hp.gas, centre, speed);
+    } else {
+        speed[0] = speed[1] = speed[2] = fp.fastest;
+    }
+
+    for (int d = 0; d < g.dim; ++d) {
+        double lo[NQ], hi[NQ];
+        if (HYDRO) {
+            const double gm1 = hp.gas.gamma - 1.0;
+            double st[SL][5];
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                const long c = c0 + (long)(s - off) * str[d];
+#pragma unroll
+                for (int n = 0; n < 5; ++n) st[s][n] = Q[c + n * g.sc];
+                st[s][H_P] = st[s][H_P] / gm1;
+            }
+            hydro_cell_faces<RECON>(hp.gas.gamma, st, lo, hi);
+        } else {
+#pragma unroll
+            for (int n = 0; n < 10; ++n) {
+                double st[SL];
+#pragma unroll
+                for (int s = 0; s < SL; ++s) st[s] = Q[c0 + (long)(s - off) * str[d] + n * g.sc];
+                recon_faces<RECON>(st, lo[n], hi[n]);
+            }
+        }
+        if (do_ctu) {
+            const double dt_2dx = 0.5 * dt / g.dx[d];
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) trace_faces(speed[d], dt_2dx, centre[n], lo[n], hi[n]);
+        }
+        double* __restrict__ plo = rlo.p[d];
+        double* __restrict__ phi = rhi.p[d];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            plo[c0 + n * g.sc] = lo[n];
+            phi[c0 + n * g.sc] = hi[n];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- face_bc
+// EulerianState::update_face_prim / face_bc, do_all branch
+// (MFP_eulerian.cpp:882-955, 794-836) for one (d, side) domain face.
+__global__ void k_face_bc(Geo g, IBox plane, int d, int side, int nq, FillRules rules, double* __restrict__ rlo,
+                          double* __restrict__ rhi) {
+    int i, j, k;
+    if (!decode(plane, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long str[3] = {1, g.sj, g.sk};
+    const long c = g.at(i, j, k);  // the cell whose low face is the plane
+    const long cm = c - str[d];
+    for (int n = 0; n < nq; ++n) {
+        const int r = rules.rule[n];
+        if (r == FILL_SKIP) continue;
+        if (side == 0) {
+            const double s = rlo[c + n * g.sc];
+            rhi[cm + n * g.sc] = (r == FILL_ODD) ? -s : s;
+        } else {
+            const double s = rhi[cm + n * g.sc];
+            rlo[c + n * g.sc] = (r == FILL_ODD) ? -s : s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- calc_fluxes
+// EulerianState::calc_fluxes MFP_eulerian.cpp:957-1045 for direction d.
+template <bool HYDRO, int FLUX>
+__global__ void k_fluxes(Geo g, IBox fbox, int d, HydroParams hp, FieldParams fp, const double* __restrict__ rlo,
+                         const double* __restrict__ rhi, double* __restrict__ flux) {
+    constexpr int NQ = HYDRO ? 5 : 10;
+    constexpr int NC = HYDRO ? 5 : 10;
+    int i, j, k;
+    if (!decode(fbox, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long str[3] = {1, g.sj, g.sk};
+    const long c = g.at(i, j, k);
+    const long cm = c - str[d];
+    double L[NQ], R[NQ], F[NC];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        L[n] = rhi[cm + n * g.sc];
+        R[n] = rlo[c + n * g.sc];
+    }
+    if (HYDRO) {
+        HydroPhys<1, FLUX>::riemann(hp, d, L, R, F);
+    } else {
+        FieldPhys<1>::riemann(fp, d, L, R, F);
+    }
+#pragma unroll
+    for (int n = 0; n < NC; ++n) flux[c + n * g.sc] = 0.0 + F[n];  // flux.setVal(0); flux += F (:987,1035)
+}
+
+// ---------------------------------------------------------- correct_face_prim
+// EulerianState::correct_face_prim MFP_eulerian.cpp:1047-1188 for face
+// direction d1: one thread per face of box + e_d1; the (DIM-1) transverse
+// corrections are applied one after the other as in the reference.
+template <bool HYDRO>
+__global__ void k_correct(Geo g, IBox faces, int d1, HydroParams hp, double* __restrict__ rlo, double* __restrict__ rhi,
+                          Ptr3 flux, double dt, int* err) {
+    constexpr int NQ = HYDRO ? 5 : 10;
+    constexpr int NC = HYDRO ? 5 : 10;
+    int i, j, k;
+    if (!decode(faces, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long str[3] = {1, g.sj, g.sk};
+    const long c = g.at(i, j, k);
+    const long cm = c - str[d1];
+    double Lp[NQ], Rp[NQ], Lc[NC], Rc[NC];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        Lp[n] = rhi[cm + n * g.sc];
+        Rp[n] = rlo[c + n * g.sc];
+    }
+    for (int dd = 1; dd < g.dim; ++dd) {
+        const int d2 = (d1 + dd) % g.dim;
+        const double* __restrict__ f = flux.p[d2];
+        if (HYDRO) {
+            hydro_prim2cons(hp.gas, Lp, Lc);
+            hydro_prim2cons(hp.gas, Rp, Rc);
+        } else {
+#pragma unroll
+            for (int n = 0; n < 10; ++n) {
+                Lc[n] = Lp[n];
+                Rc[n] = Rp[n];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            double loF = f[cm + n * g.sc];
+            double hiF = f[cm + str[d2] + n * g.sc];
+            Lc[n] += 0.5 * dt / g.dx[d2] * (loF - hiF);
+        }
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            double loF = f[c + n * g.sc];
+            double hiF = f[c + str[d2] + n * g.sc];
+            Rc[n] += 0.5 * dt / g.dx[d2] * (loF - hiF);
+        }
+        if (HYDRO) {
+            if (!hydro_cons2prim(hp.gas, Lc, Lp)) *err = 1;
+            if (!hydro_cons2prim(hp.gas, Rc, Rp)) *err = 1;
+        } else {
+#pragma unroll
+            for (int n = 0; n < 10; ++n) {
+                Lp[n] = Lc[n];
+                Rp[n] = Rc[n];
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        rhi[cm + n * g.sc] = Lp[n];
+        rlo[c + n * g.sc] = Rp[n];
+    }
+}
+
+// ------------------------------------------------------------ calc_divergence
+// EulerianState::calc_divergence MFP_eulerian.cpp:1614-1662
+__global__ void k_divergence(Geo g, IBox box, int nc, Ptr3 flux, double* __restrict__ dU, double dt) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long str[3] = {1, g.sj, g.sk};
+    const long c = g.at(i, j, k);
+    for (int n = 0; n < nc; ++n) {
+        double du = 0.0;
+        for (int d = 0; d < g.dim; ++d) {
+            const double dxinv = dt / g.dx[d];
+            const double flux_lo = flux.p[d][c + n * g.sc];
+            const double flux_hi = flux.p[d][c + str[d] + n * g.sc];
+            du += dxinv * (flux_lo - flux_hi);
+        }
+        dU[c + n * g.sc] = du;
+    }
+}
+
+// ------------------------------------------------------- MultiFab-level helpers
+// MultiFab::Copy / setVal / Add / LinComb on the valid cells (ng = 0), as used by
+// Action::get_data (MFP_action.cpp:79,98) and advance_* (MFP_advance.cpp).
+__global__ void k_copy(Geo g, IBox box, int nc, double* __restrict__ dst, const double* __restrict__ src) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long c = g.at(i, j, k);
+    for (int n = 0; n < nc; ++n) dst[c + n * g.sc] = src[c + n * g.sc];
+}
+__global__ void k_zero(Geo g, IBox box, int nc, double* __restrict__ dst) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long c = g.at(i, j, k);
+    for (int n = 0; n < nc; ++n) dst[c + n * g.sc] = 0.0;
+}
+__global__ void k_add(Geo g, IBox box, int nc, double* __restrict__ dst, const double* __restrict__ src) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long c = g.at(i, j, k);
+    for (int n = 0; n < nc; ++n) dst[c + n * g.sc] += src[c + n * g.sc];
+}
+__global__ void k_lincomb(Geo g, IBox box, int nc, double* dst, double a, const double* x, double b, const double* y) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long c = g.at(i, j, k);
+    for (int n = 0; n < nc; ++n) dst[c + n * g.sc] = a * x[c + n * g.sc] + b * y[c + n * g.sc];
+}
+
+// -------------------------------------------------------------------- sources
+struct SourceCoef {
+    double f1, f2, f3;
+};
+static SourceCoef source_coef(const SourceArgs& a, double dt) {
+    // MFP_plasma5.cpp:123-129
+    const double c_h = a.c_h;
+    const double c_d = a.div_damp != 0.0 ? c_h / a.div_damp : 0.0;
+    SourceCoef k;
+    k.f1 = dt * a.Larmor / (a.Debye * a.Debye * a.lightspeed);
+    k.f2 = dt * c_h * c_h * k.f1 / a.lightspeed;
+    k.f3 = c_d != 0.0 ? dt * c_h * c_h / (c_d * c_d) : 0.0;
+    return k;
+}
+
+// One cell of Plasma5::explicit_solve (MFP_plasma5.cpp:161-236) /
+// Lorentz::calc_time_derivative (MFP_lorentz.cpp:129-189).  fU: field comps,
+// sU[n]: species comps {rho,mx,my,mz,E}.  Outputs are the increments.
+template <int MAXS>
+CMFP_DEV void plasma5_explicit_cell(const SourceArgs& a, const SourceCoef& kf, double dt, const double* fU,
+                                    const double (*sU)[5], double (*sdU)[4], double* fdU /*Dx,Dy,Dz,phi,psi*/) {
+    const double Larmor = a.Larmor, lightspeed = a.lightspeed;
+    const double ep = fU[F_EP];
+    const double Bx = fU[F_BX], By = fU[F_BY], Bz = fU[F_BZ];
+    const double Ex = fU[F_DX] / ep, Ey = fU[F_DY] / ep, Ez = fU[F_DZ] / ep;
+    double charge_density = 0.0, current_x = 0.0, current_y = 0.0, current_z = 0.0;
+#pragma unroll
+    for (int n = 0; n < MAXS; ++n) {
+        if (n < a.n_species) {
+            const double rho = sU[n][0], mx = sU[n][1], my = sU[n][2], mz = sU[n][3];
+            const double r = a.r[n];
+            charge_density += rho * r;
+            current_x += r * mx;
+            current_y += r * my;
+            current_z += r * mz;
+            const double u = mx / rho, v = my / rho, w = mz / rho;
+            sdU[n][0] = dt * (rho * r / Larmor) * (lightspeed * Ex + v * Bz - w * By);
+            sdU[n][1] = dt * (rho * r / Larmor) * (lightspeed * Ey + w * Bx - u * Bz);
+            sdU[n][2] = dt * (rho * r / Larmor) * (lightspeed * Ez + u * By - v * Bx);
+            sdU[n][3] = dt * (rho * r * lightspeed) / Larmor * (u * Ex + v * Ey + w * Ez);
+        }
+    }
+    fdU[0] = -kf.f1 * current_x;
+    fdU[1] = -kf.f1 * current_y;
+    fdU[2] = -kf.f1 * current_z;
+    fdU[3] = -fU[F_PHI] * kf.f3 + kf.f2 * charge_density;
+    fdU[4] = -fU[F_PSI] * kf.f3;
+}
+
+// One cell of Plasma5::implicit_solve (MFP_plasma5.cpp:324-448).  The
+// reference factors the dense 3(Ns+1) system with Eigen's ColPivHouseholderQR;
+// here the same linear system
+//     (I + mc_n [B]x) m_n + tB_n E = m_n^0 ,   E + sum_n tC_n m_n = E^0
+// is solved in registers by block elimination: (I + [a]x)^-1 =
+// (I + a a^T - [a]x) / (1 + |a|^2) in closed form per species, then one 3x3
+// Schur system for E.  Same solution to rounding (tested to 1e-12).
+template <int MAXS>
+CMFP_DEV void plasma5_implicit_cell(const SourceArgs& a, const SourceCoef& kf, double dt, const double* fU,
+                                    const double (*sU)[5], double (*sdU)[4], double* fdU) {
+    const double Larmor = a.Larmor, Debye = a.Debye, lightspeed = a.lightspeed;
+    const double ep = fU[F_EP];
+    const double B[3] = {fU[F_BX], fU[F_BY], fU[F_BZ]};
+    const double E0[3] = {fU[F_DX] / ep, fU[F_DY] / ep, fU[F_DZ] / ep};
+    double charge_density = 0.0;
+    double S[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    double rhs[3] = {E0[0], E0[1], E0[2]};
+    double Minv[MAXS][3][3];
+    double tB[MAXS];
+#pragma unroll
+    for (int n = 0; n < MAXS; ++n) {
+        if (n < a.n_species) {
+            const double rho = sU[n][0];
+            const double r = a.r[n];
+            charge_density += rho * r;
+            charge_density += rho * r;  // MFP_plasma5.cpp:370-372 counts it twice (quirk Q3)
+            const double trace_B = -dt * r * rho * lightspeed / Larmor;
+            const double trace_C = dt * r * Larmor / (lightspeed * Debye * Debye);
+            const double mc = dt * r / Larmor;
+            tB[n] = trace_B;
+            const double av[3] = {mc * B[0], mc * B[1], mc * B[2]};
+            const double den = 1.0 + (av[0] * av[0] + av[1] * av[1] + av[2] * av[2]);
+            // (I + a a^T - [a]x) / den ;  [a]x = {{0,-az,ay},{az,0,-ax},{-ay,ax,0}}
+            const double ax[3][3] = {{0, -av[2], av[1]}, {av[2], 0, -av[0]}, {-av[1], av[0], 0}};
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Minv[n][p][q] = ((p == q ? 1.0 : 0.0) + av[p] * av[q] - ax[p][q]) / den;
+            const double m0[3] = {sU[n][1], sU[n][2], sU[n][3]};
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                double mm = Minv[n][p][0] * m0[0] + Minv[n][p][1] * m0[1] + Minv[n][p][2] * m0[2];
+                rhs[p] -= trace_C * mm;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) S[p][q] -= trace_C * trace_B * Minv[n][p][q];
+            }
+        }
+    }
+    // 3x3 solve by cofactors
+    const double c00 = S[1][1] * S[2][2] - S[1][2] * S[2][1];
+    const double c01 = S[1][2] * S[2][0] - S[1][0] * S[2][2];
+    const double c02 = S[1][0] * S[2][1] - S[1][1] * S[2][0];
+    const double det = S[0][0] * c00 + S[0][1] * c01 + S[0][2] * c02;
+    const double c10 = S[0][2] * S[2][1] - S[0][1] * S[2][2];
+    const double c11 = S[0][0] * S[2][2] - S[0][2] * S[2][0];
+    const double c12 = S[0][1] * S[2][0] - S[0][0] * S[2][1];
+    const double c20 = S[0][1] * S[1][2] - S[0][2] * S[1][1];
+    const double c21 = S[0][2] * S[1][0] - S[0][0] * S[1][2];
+    const double c22 = S[0][0] * S[1][1] - S[0][1] * S[1][0];
+    double E[3];
+    E[0] = (c00 * rhs[0] + c10 * rhs[1] + c20 * rhs[2]) / det;
+    E[1] = (c01 * rhs[0] + c11 * rhs[1] + c21 * rhs[2]) / det;
+    E[2] = (c02 * rhs[0] + c12 * rhs[1] + c22 * rhs[2]) / det;
+
+    fdU[0] = E[0] * ep - fU[F_DX];
+    fdU[1] = E[1] * ep - fU[F_DY];
+    fdU[2] = E[2] * ep - fU[F_DZ];
+#pragma unroll
+    for (int n = 0; n < MAXS; ++n) {
+        if (n < a.n_species) {
+            const double m0[3] = {sU[n][1], sU[n][2], sU[n][3]};
+            const double b[3] = {m0[0] - tB[n] * E[0], m0[1] - tB[n] * E[1], m0[2] - tB[n] * E[2]};
+            double m[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) m[p] = Minv[n][p][0] * b[0] + Minv[n][p][1] * b[1] + Minv[n][p][2] * b[2];
+            sdU[n][0] = m[0] - m0[0];
+            sdU[n][1] = m[1] - m0[1];
+            sdU[n][2] = m[2] - m0[2];
+            sdU[n][3] = dt * (a.r[n] * lightspeed / Larmor) * (E[0] * m[0] + E[1] * m[1] + E[2] * m[2]);
+        }
+    }
+    fdU[3] = -fU[F_PHI] * kf.f3 + kf.f2 * charge_density;
+    fdU[4] = -fU[F_PSI] * kf.f3;
+}
+
+// staged form: dU += S(U) on the valid cells (Plasma5::calc_time_derivative
+// MFP_plasma5.cpp:73-85, Lorentz::calc_time_derivative MFP_lorentz.cpp:60-198)
+__global__ void k_source(Geo g, IBox box, SourceArgs a, SourceCoef kf, double dt) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long c = g.at(i, j, k);
+    double fU[10], sU[4][5], sdU[4][4], fdU[5];
+#pragma unroll
+    for (int n = 0; n < 10; ++n) fU[n] = a.f_U[c + n * g.sc];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < a.n_species) {
+#pragma unroll
+            for (int n = 0; n < 5; ++n) sU[s][n] = a.sp_U[s][c + n * g.sc];
+        }
+    if (a.implicit)
+        plasma5_implicit_cell<4>(a, kf, dt, fU, sU, sdU, fdU);
+    else
+        plasma5_explicit_cell<4>(a, kf, dt, fU, sU, sdU, fdU);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < a.n_species) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) a.sp_dU[s][c + (n + 1) * g.sc] += sdU[s][n];
+        }
+    if (!a.lorentz_only) {
+        a.f_dU[c + F_DX * g.sc] += fdU[0];
+        a.f_dU[c + F_DY * g.sc] += fdU[1];
+        a.f_dU[c + F_DZ * g.sc] += fdU[2];
+        a.f_dU[c + F_PHI * g.sc] += fdU[3];
+        a.f_dU[c + F_PSI * g.sc] += fdU[4];
+    }
+}
+
+// fused form of one Strang source stage with the RK2 inner integrator
+// (MFP_advance.cpp:146-197 / 235-281), in place on the new-time data:
+//   U1 = U0 + S(U0) ; U2 = U1 + S(U1) ; new = 0.5 U0 + 0.5 U2
+// Components no source touches are left as they are (the reference rewrites
+// them with 0.5 x + 0.5 (x + 0 + 0) = x).
+__global__ void k_source_rk2(Geo g, IBox box, SourceArgs a, SourceCoef kf, double dt) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long c = g.at(i, j, k);
+    double f0[10], s0[4][5], f1[10], s1[4][5], sdU[4][4], fdU[5];
+#pragma unroll
+    for (int n = 0; n < 10; ++n) f0[n] = a.f_U[c + n * g.sc];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < a.n_species) {
+#pragma unroll
+            for (int n = 0; n < 5; ++n) s0[s][n] = a.sp_U[s][c + n * g.sc];
+        }
+    // stage 1
+    if (a.implicit)
+        plasma5_implicit_cell<4>(a, kf, dt, f0, s0, sdU, fdU);
+    else
+        plasma5_explicit_cell<4>(a, kf, dt, f0, s0, sdU, fdU);
+#pragma unroll
+    for (int n = 0; n < 10; ++n) f1[n] = f0[n];
+    if (!a.lorentz_only) {
+        f1[F_DX] = f0[F_DX] + fdU[0];
+        f1[F_DY] = f0[F_DY] + fdU[1];
+        f1[F_DZ] = f0[F_DZ] + fdU[2];
+        f1[F_PHI] = f0[F_PHI] + fdU[3];
+        f1[F_PSI] = f0[F_PSI] + fdU[4];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < a.n_species) {
+            s1[s][0] = s0[s][0];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) s1[s][n + 1] = s0[s][n + 1] + sdU[s][n];
+        }
+    // stage 2
+    if (a.implicit)
+        plasma5_implicit_cell<4>(a, kf, dt, f1, s1, sdU, fdU);
+    else
+        plasma5_explicit_cell<4>(a, kf, dt, f1, s1, sdU, fdU);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < a.n_species) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const double U2 = s1[s][n + 1] + sdU[s][n];
+                a.sp_U[s][c + (n + 1) * g.sc] = 0.5 * s0[s][n + 1] + 0.5 * U2;
+            }
+        }
+    if (!a.lorentz_only) {
+        a.f_U[c + F_DX * g.sc] = 0.5 * f0[F_DX] + 0.5 * (f1[F_DX] + fdU[0]);
+        a.f_U[c + F_DY * g.sc] = 0.5 * f0[F_DY] + 0.5 * (f1[F_DY] + fdU[1]);
+        a.f_U[c + F_DZ * g.sc] = 0.5 * f0[F_DZ] + 0.5 * (f1[F_DZ] + fdU[2]);
+        a.f_U[c + F_PHI * g.sc] = 0.5 * f0[F_PHI] + 0.5 * (f1[F_PHI] + fdU[3]);
+        a.f_U[c + F_PSI * g.sc] = 0.5 * f0[F_PSI] + 0.5 * (f1[F_PSI] + fdU[4]);
+    }
+}
+
+// ------------------------------------------------------------- dt reductions
+// Positive doubles order like their bit patterns, so the chip-wide max / min
+// is one 64-bit integer atomic per block after a wave64 shuffle reduction.
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// EulerianState::get_allowed_time_step MFP_eulerian.cpp:255-300: max over valid
+// cells and over d < DIM of get_speed_from_cons.
+__global__ void k_max_speed(Geo g, IBox box, HydroParams hp, const double* __restrict__ U, unsigned long long* out) {
+    __shared__ double part[TPB / 64];
+    int i, j, k;
+    double m = DBL_MIN;  // std::numeric_limits<Real>::min()  (:265)
+    if (decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) {
+        const long c = g.at(i, j, k);
+        double u[5], s[3];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) u[n] = U[c + n * g.sc];
+        hydro_speed_from_cons(hp.gas, u, s);
+        for (int d = 0; d < g.dim; ++d) m = std_max(m, s[d]);
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; ++w) m = fmax(m, part[w]);
+        atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+// Plasma5::get_allowed_time_step MFP_plasma5.cpp:522-557 (cell loop part)
+__global__ void k_plasma_dt(Geo g, IBox box, SourceArgs a, unsigned long long* out) {
+    __shared__ double part[TPB / 64];
+    int i, j, k;
+    double dt = DBL_MAX;
+    if (decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) {
+        const long c = g.at(i, j, k);
+        const double PI = 3.141592653589793;  // acos(-1)
+        const double D2 = a.Debye * a.Debye;
+        const double Bx = a.f_U[c + F_BX * g.sc], By = a.f_U[c + F_BY * g.sc], Bz = a.f_U[c + F_BZ * g.sc];
+        const double B = sqrt(Bx * Bx + By * By + Bz * Bz);
+        for (int n = 0; n < a.n_species; ++n) {
+            const double rho = a.sp_U[n][c];
+            const double r = a.r[n];
+            const double omega_p = 10 * sqrt(rho * r * r / D2) / (2 * PI);
+            if (omega_p > 0) dt = std_min(dt, 1 / omega_p);
+            const double omega_c = 10 * (fabs(r) * B) / (a.Larmor * 2 * PI);
+            if (omega_c > 0) dt = std_min(dt, 1 / omega_c);
+        }
+    }
+    dt = wave_min(dt);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = dt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; ++w) dt = fmin(dt, part[w]);
+        atomicMin(out, (unsigned long long)__double_as_longlong(dt));
+    }
+}
+
+// ------------------------------------------------------------------ ghosts
+// One (dim, side) sweep of the ghost fill: fab_filcc semantics (dimension by
+// dimension over the full extent of the other dimensions) + periodic wrap.
+__global__ void k_fill_dim(Geo g, IBox slab, int nc, int ngs, int d, int side, FillRules rules, double* __restrict__ A) {
+    int c3[3];
+    if (!decode(slab, (long)blockIdx.x * TPB + threadIdx.x, c3[0], c3[1], c3[2])) return;
+    // slab coordinate along d is the layer 1..ngs
+    const int layer = c3[d];
+    const int n = g.n[d];
+    const int idst = side == 0 ? -layer : n - 1 + layer;
+    int s3[3] = {c3[0], c3[1], c3[2]};
+    c3[d] = idst;
+    const long cd = g.at(c3[0], c3[1], c3[2]);
+    for (int m = 0; m < nc; ++m) {
+        const int r = rules.rule[m];
+        if (r == FILL_SKIP) continue;
+        int isrc;
+        if (r == FILL_WRAP)
+            isrc = side == 0 ? n - layer : layer - 1;
+        else if (r == FILL_FOEXTRAP)
+            isrc = side == 0 ? 0 : n - 1;
+        else
+            isrc = side == 0 ? layer - 1 : n - layer;
+        s3[d] = isrc;
+        const double v = A[g.at(s3[0], s3[1], s3[2]) + m * g.sc];
+        A[cd + m * g.sc] = (r == FILL_ODD) ? -v : v;
+    }
+}
+
+// halo pack / unpack of the ngs layers next to a face; the slab spans the full
+// ghosted extent of the other dimensions.
+__global__ void k_pack(Geo g, IBox slab, int nc, int d, int first, double* __restrict__ A, double* __restrict__ buf, int unpack) {
+    const long t = (long)blockIdx.x * TPB + threadIdx.x;
+    int c3[3];
+    if (!decode(slab, t, c3[0], c3[1], c3[2])) return;
+    const long np = slab.npts();
+    c3[d] = first + (c3[d] - slab.lo[d]);
+    const long c = g.at(c3[0], c3[1], c3[2]);
+    for (int m = 0; m < nc; ++m) {
+        if (unpack)
+            A[c + m * g.sc] = buf[t + m * np];
+        else
+            buf[t + m * np] = A[c + m * g.sc];
+    }
+}
+
+// ------------------------------------------------------------- leaf kernels
+template <int RECON> __global__ void k_leaf_recon(long n, const double* st, double* slope, double* lo, double* hi) {
+    const long t = (long)blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    constexpr int SL = ReconTraits<RECON>::SL;
+    double s[SL];
+#pragma unroll
+    for (int q = 0; q < SL; ++q) s[q] = st[q * n + t];
+    slope[t] = recon_slope<RECON>(s);
+    double l = 0, h = 0;
+    recon_faces<RECON>(s, l, h);
+    lo[t] = l;
+    hi[t] = h;
+}
+template <int FLUX> __global__ void k_leaf_riemann_hydro(long n, const double* L, const double* R, double* F, double thr) {
+    const long t = (long)blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    double l[5], r[5], f[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        l[q] = L[q * n + t];
+        r[q] = R[q * n + t];
+    }
+    const double gL = L[6 * n + t], gR = R[6 * n + t];
+    if (FLUX == 0)
+        hllc_solve(l, r, gL, gR, f);
+    else if (FLUX == 1)
+        hlle_solve(l, r, gL, gR, f);
+    else
+        hybrid_solve(l, r, gL, gR, shock_detect(l, r, thr), f);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) F[q * n + t] = f[q];
+}
+__global__ void k_leaf_riemann_field(long n, const double* L, const double* R, double* F, double c0, double ch) {
+    const long t = (long)blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    double l[10], r[10], f[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        l[q] = L[q * n + t];
+        r[q] = R[q * n + t];
+    }
+    field_rh_solve(c0, ch, l, r, f);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) F[q * n + t] = f[q];
+}
+__global__ void k_leaf_cons2prim(long n, GasP G, const double* U, double* Q, double* sp) {
+    const long t = (long)blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    double u[5], q[5], s[3];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) u[c] = U[c * n + t];
+    hydro_cons2prim(G, u, q);
+    hydro_speed_from_cons(G, u, s);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) Q[c * n + t] = q[c];
+    // T, gamma, cp as ThermallyPerfectGas::cons2prim reports them (:202,210-211)
+    Q[5 * n + t] = q[H_P] * (1 / u[0]) * G.mass;
+    Q[6 * n + t] = G.gamma;
+    Q[7 * n + t] = G.gamma / (G.mass * (G.gamma - 1));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sp[c * n + t] = s[c];
+}
+__global__ void k_leaf_prim2cons(long n, GasP G, const double* Q, double* U) {
+    const long t = (long)blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    double u[5], q[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) q[c] = Q[c * n + t];
+    hydro_prim2cons(G, q, u);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) U[c * n + t] = u[c];
+}
+
+// ===========================================================================
+// host launchers
+#define LAUNCH(kern, npts, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3(nblocks(npts)), dim3(TPB), 0, stream, __VA_ARGS__)
+
+static void l_prim(const Geo& g, const StatePhys& sp, const double* U, double* Q, int* err, hipStream_t st) {
+    IBox b = grown_box(g, sp.ng);
+    if (sp.kind == 0)
+        LAUNCH(k_prim<true>, b.npts(), st, g, b, sp.hp, U, Q, err);
+    else
+        LAUNCH(k_prim<false>, b.npts(), st, g, b, sp.hp, U, Q, err);
+}
+
+template <bool HYDRO>
+static void l_recon_t(const Geo& g, const StatePhys& sp, const double* Q, Ptr3 rlo, Ptr3 rhi, int do_ctu, double dt,
+                      hipStream_t st) {
+    IBox b = grown_box(g, 1);
+    const long n = b.npts();
+    switch (sp.recon) {
+    case 0: LAUNCH((k_recon<HYDRO, 0>), n, st, g, b, sp.hp, sp.fp, Q, rlo, rhi, do_ctu, dt); break;
+    case 1: LAUNCH((k_recon<HYDRO, 1>), n, st, g, b, sp.hp, sp.fp, Q, rlo, rhi, do_ctu, dt); break;
+    case 2: LAUNCH((k_recon<HYDRO, 2>), n, st, g, b, sp.hp, sp.fp, Q, rlo, rhi, do_ctu, dt); break;
+    case 3: LAUNCH((k_recon<HYDRO, 3>), n, st, g, b, sp.hp, sp.fp, Q, rlo, rhi, do_ctu, dt); break;
+    case 4: LAUNCH((k_recon<HYDRO, 4>), n, st, g, b, sp.hp, sp.fp, Q, rlo, rhi, do_ctu, dt); break;
+    case 5: LAUNCH((k_recon<HYDRO, 5>), n, st, g, b, sp.hp, sp.fp, Q, rlo, rhi, do_ctu, dt); break;
+    case 6: LAUNCH((k_recon<HYDRO, 6>), n, st, g, b, sp.hp, sp.fp, Q, rlo, rhi, do_ctu, dt); break;
+    }
+}
+static void l_recon(const Geo& g, const StatePhys& sp, const double* Q, Ptr3 rlo, Ptr3 rhi, int do_ctu, double dt,
+                    hipStream_t st) {
+    if (sp.kind == 0)
+        l_recon_t<true>(g, sp, Q, rlo, rhi, do_ctu, dt, st);
+    else
+        l_recon_t<false>(g, sp, Q, rlo, rhi, do_ctu, dt, st);
+}
+
+static FillRules face_rules(const StatePhys& sp, int d, int side) {
+    // MFP_eulerian.cpp:796-835: foextrap / hoextrap / reflect_even copy, reflect_odd negates
+    FillRules r;
+    for (int n = 0; n < 10; ++n) {
+        int bc = (n < sp.nc) ? sp.bc[n][d][side] : -666;
+        r.rule[n] = (bc == 2 || bc == 4 || bc == 1) ? FILL_EVEN : (bc == -1 ? FILL_ODD : FILL_SKIP);
+    }
+    return r;
+}
+static void l_face_bc(const Geo& g, const StatePhys& sp, int d, int side, double* rlo, double* rhi, hipStream_t st) {
+    IBox pl = valid_box(g);
+    pl.lo[d] = pl.hi[d] = (side == 0) ? 0 : g.n[d];
+    LAUNCH(k_face_bc, pl.npts(), st, g, pl, d, side, sp.nq, face_rules(sp, d, side), rlo, rhi);
+}
+
+static void l_fluxes(const Geo& g, const StatePhys& sp, int d, const double* rlo, const double* rhi, double* flux,
+                     int grown, hipStream_t st) {
+    IBox fb = valid_box(g);
+    fb.hi[d] += 1;  // surroundingNodes(box, d)
+    if (grown)      // MFP_CTU_hydro.cpp:256-262
+        for (int t = 0; t < g.dim; ++t)
+            if (t != d) {
+                fb.lo[t] -= 1;
+                fb.hi[t] += 1;
+            }
+    const long n = fb.npts();
+    if (sp.kind == 0) {
+        switch (sp.flux) {
+        case 0: LAUNCH((k_fluxes<true, 0>), n, st, g, fb, d, sp.hp, sp.fp, rlo, rhi, flux); break;
+        case 1: LAUNCH((k_fluxes<true, 1>), n, st, g, fb, d, sp.hp, sp.fp, rlo, rhi, flux); break;
+        default: LAUNCH((k_fluxes<true, 2>), n, st, g, fb, d, sp.hp, sp.fp, rlo, rhi, flux); break;
+        }
+    } else {
+        LAUNCH((k_fluxes<false, 0>), n, st, g, fb, d, sp.hp, sp.fp, rlo, rhi, flux);
+    }
+}
+
+static void l_correct(const Geo& g, const StatePhys& sp, int d1, double* rlo, double* rhi, Ptr3 flux, double dt,
+                      int* err, hipStream_t st) {
+    IBox fb = valid_box(g);
+    fb.hi[d1] += 1;  // MFP_eulerian.cpp:1100-1103
+    if (sp.kind == 0)
+        LAUNCH(k_correct<true>, fb.npts(), st, g, fb, d1, sp.hp, rlo, rhi, flux, dt, err);
+    else
+        LAUNCH(k_correct<false>, fb.npts(), st, g, fb, d1, sp.hp, rlo, rhi, flux, dt, err);
+}
+
+static void l_divergence(const Geo& g, int nc, Ptr3 flux, double* dU, double dt, hipStream_t st) {
+    IBox b = valid_box(g);
+    LAUNCH(k_divergence, b.npts(), st, g, b, nc, flux, dU, dt);
+}
+
+static void l_copy(const Geo& g, int nc, double* dst, const double* src, int with_ghosts, hipStream_t st) {
+    IBox b = with_ghosts ? grown_box(g, g.ng[0]) : valid_box(g);
+    LAUNCH(k_copy, b.npts(), st, g, b, nc, dst, src);
+}
+static void l_zero(const Geo& g, int nc, double* dst, hipStream_t st) {
+    IBox b = valid_box(g);
+    LAUNCH(k_zero, b.npts(), st, g, b, nc, dst);
+}
+static void l_add(const Geo& g, int nc, double* dst, const double* src, hipStream_t st) {
+    IBox b = valid_box(g);
+    LAUNCH(k_add, b.npts(), st, g, b, nc, dst, src);
+}
+static void l_lincomb(const Geo& g, int nc, double* dst, double a, const double* x, double bb, const double* y,
+                      hipStream_t st) {
+    IBox b = valid_box(g);
+    LAUNCH(k_lincomb, b.npts(), st, g, b, nc, dst, a, x, bb, y);
+}
+
+static void l_source(const Geo& g, const SourceArgs& a, double dt, hipStream_t st) {
+    IBox b = valid_box(g);
+    LAUNCH(k_source, b.npts(), st, g, b, a, source_coef(a, dt), dt);
+}
+static int l_source_fused(const Geo& g, const SourceArgs& a, double dt, hipStream_t st) {
+    IBox b = valid_box(g);
+    LAUNCH(k_source_rk2, b.npts(), st, g, b, a, source_coef(a, dt), dt);
+    return 1;
+}
+
+static void l_max_speed(const Geo& g, const StatePhys& sp, const double* U, unsigned long long* out, hipStream_t st) {
+    IBox b = valid_box(g);
+    LAUNCH(k_max_speed, b.npts(), st, g, b, sp.hp, U, out);
+}
+static void l_plasma_dt(const Geo& g, const SourceArgs& a, unsigned long long* out, hipStream_t st) {
+    IBox b = valid_box(g);
+    LAUNCH(k_plasma_dt, b.npts(), st, g, b, a, out);
+}
+
+static IBox ghost_slab(const Geo& g, int d, int ngs, int lo_other_full) {
+    // other dims: full ghosted extent; dim d: ngs layers (coordinates 1..ngs / 0..ngs-1 set by caller)
+    IBox s;
+    for (int t = 0; t < 3; ++t) {
+        s.lo[t] = -g.ng[t];
+        s.hi[t] = g.n[t] - 1 + g.ng[t];
+    }
+    (void)lo_other_full;
+    s.lo[d] = 1;
+    s.hi[d] = ngs;
+    return s;
+}
+static void l_fill_dim(const Geo& g, int nc, int ngs, double* A, int d, int side, FillRules rules, hipStream_t st) {
+    IBox s = ghost_slab(g, d, ngs, 1);
+    LAUNCH(k_fill_dim, s.npts(), st, g, s, nc, ngs, d, side, rules, A);
+}
+static void l_pack(const Geo& g, int nc, int ngs, double* A, int d, int side, double* buf, int unpack, hipStream_t st) {
+    IBox s = ghost_slab(g, d, ngs, 1);
+    int first;
+    if (!unpack)
+        first = side == 0 ? 0 : g.n[d] - ngs;  // valid layers next to the face
+    else
+        first = side == 0 ? -ngs : g.n[d];     // ghost layers
+    LAUNCH(k_pack, s.npts(), st, g, s, nc, d, first, A, buf, unpack);
+}
+
+static int l_leaf_reconstruct(int recon, long n, const double* s, double* slope, double* lo, double* hi, hipStream_t st) {
+    switch (recon) {
+    case 0: LAUNCH(k_leaf_recon<0>, n, st, n, s, slope, lo, hi); break;
+    case 1: LAUNCH(k_leaf_recon<1>, n, st, n, s, slope, lo, hi); break;
+    case 2: LAUNCH(k_leaf_recon<2>, n, st, n, s, slope, lo, hi); break;
+    case 3: LAUNCH(k_leaf_recon<3>, n, st, n, s, slope, lo, hi); break;
+    case 4: LAUNCH(k_leaf_recon<4>, n, st, n, s, slope, lo, hi); break;
+    case 5: LAUNCH(k_leaf_recon<5>, n, st, n, s, slope, lo, hi); break;
+    case 6: LAUNCH(k_leaf_recon<6>, n, st, n, s, slope, lo, hi); break;
+    default: return 0;
+    }
+    return 1;
+}
+static int l_leaf_riemann(int flux, long n, const double* L, const double* R, double* F, double c0, double ch, double thr,
+                          hipStream_t st) {
+    switch (flux) {
+    case 0: LAUNCH(k_leaf_riemann_hydro<0>, n, st, n, L, R, F, thr); break;
+    case 1: LAUNCH(k_leaf_riemann_hydro<1>, n, st, n, L, R, F, thr); break;
+    case 2: LAUNCH(k_leaf_riemann_hydro<2>, n, st, n, L, R, F, thr); break;
+    case 10: LAUNCH(k_leaf_riemann_field, n, st, n, L, R, F, c0, ch); break;
+    default: return 0;
+    }
+    return 1;
+}
+static int l_leaf_cons2prim(long n, double mass, double gamma, const double* U, double* Q, double* sp, hipStream_t st) {
+    GasP G{mass, 0.0, gamma};
+    LAUNCH(k_leaf_cons2prim, n, st, n, G, U, Q, sp);
+    return 1;
+}
+static int l_leaf_prim2cons(long n, double mass, double gamma, const double* Q, double* U, hipStream_t st) {
+    GasP G{mass, 0.0, gamma};
+    LAUNCH(k_leaf_prim2cons, n, st, n, G, Q, U);
+    return 1;
+}
+
+// defined in mfp_fused.hip
+int ctu_fused(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
+              const int touches[3][2], int* err, hipStream_t);
+
+const Launchers* launchers() {
+    static const Launchers L = {l_prim,      l_recon,         l_face_bc,        l_fluxes,          l_correct,
+                                l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
+                                l_source,    l_max_speed,     l_plasma_dt,      l_fill_dim,        l_pack,
+                                ctu_fused,   l_source_fused,  l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
+                                l_leaf_prim2cons};
+    return &L;
+}
+
+}  // namespace CMFP_NS

@@ -1,0 +1,126 @@
+// mfp_types.h — POD types shared by the context (host) and the kernel TUs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cmfp {
+
+struct GasP {
+    double mass, charge, gamma;
+};
+struct HydroParams {
+    GasP gas;
+    double shock_threshold;
+};
+struct FieldParams {
+    double c0;       // MFP::lightspeed
+    double ch;       // div_speed = div_transport * lightspeed  (MFP_field.cpp:384)
+    double fastest;  // max(c0, ch)                             (MFP_field.cpp:386)
+};
+
+// Geometry of one state's ghosted SoA arrays on this block: local cell
+// (i,j,k), 0 <= i < n[0], ghosts at negative / >= n indices; i fastest,
+// component slowest (the FArrayBox layout).
+struct Geo {
+    int dim;
+    int n[3];
+    int ng[3];   // ghost width (0 in unused dims)
+    int ext[3];  // n + 2 ng
+    long sj, sk, sc;
+    double dx[3];
+    __host__ __device__ long at(int i, int j, int k) const {
+        return (long)(i + ng[0]) + (long)(j + ng[1]) * sj + (long)(k + ng[2]) * sk;
+    }
+    __host__ __device__ long cells() const { return sc; }
+};
+
+struct IBox {
+    int lo[3], hi[3];
+    __host__ __device__ long npts() const {
+        return (long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+    }
+};
+
+struct StatePhys {
+    int kind;   // cmfp_state_kind
+    int recon;  // cmfp_recon
+    int flux;   // cmfp_flux
+    int nc;     // conserved comps (5 / 10)
+    int nq;     // primitive comps carried (5 / 10)
+    int ng;     // Reconstruction::num_grow of this state (<= the context's common ghost width)
+    HydroParams hp;
+    FieldParams fp;
+    int bc[10][3][2];
+};
+
+struct Ptr3 {
+    double* p[3];
+};
+
+// species list of a plasma5 / Lorentz action
+struct SourceArgs {
+    int n_species;
+    double* sp_U[4];   // species conserved data read
+    double* sp_dU[4];  // species dU accumulated (staged) or output (fused)
+    double r[4];       // charge / mass  (q / m, MFP_plasma5.cpp:202)
+    double* f_U;
+    double* f_dU;
+    long sp_sc[4];  // component strides
+    long f_sc;
+    double Larmor, Debye, lightspeed;
+    double c_h, div_damp;
+    int lorentz_only;
+    int implicit;
+};
+
+// ghost fill rule per component for one (dim, side)
+enum FillRule { FILL_SKIP = 0, FILL_WRAP = 1, FILL_FOEXTRAP = 2, FILL_EVEN = 3, FILL_ODD = 4 };
+struct FillRules {
+    int rule[10];
+};
+
+// Host-side launchers of one floating-point mode (namespace strict / fast).
+struct Launchers {
+    // staged kernels: one per FAB-level function of the reference
+    void (*prim)(const Geo&, const StatePhys&, const double* U, double* prim, int* err, hipStream_t);
+    void (*recon)(const Geo&, const StatePhys&, const double* prim, Ptr3 rlo, Ptr3 rhi, int do_ctu, double dt,
+                  hipStream_t);
+    void (*face_bc)(const Geo&, const StatePhys&, int d, int side, double* rlo, double* rhi, hipStream_t);
+    void (*fluxes)(const Geo&, const StatePhys&, int d, const double* rlo, const double* rhi, double* flux,
+                   int grown, hipStream_t);
+    void (*correct)(const Geo&, const StatePhys&, int d1, double* rlo, double* rhi, Ptr3 flux, double dt, int* err,
+                    hipStream_t);
+    void (*divergence)(const Geo&, int nc, Ptr3 flux, double* dU, double dt, hipStream_t);
+    // valid-cell elementwise ops
+    void (*copy)(const Geo&, int nc, double* dst, const double* src, int with_ghosts, hipStream_t);
+    void (*zero)(const Geo&, int nc, double* dst, hipStream_t);
+    void (*add)(const Geo&, int nc, double* dst, const double* src, hipStream_t);
+    void (*lincomb)(const Geo&, int nc, double* dst, double a, const double* x, double b, const double* y,
+                    hipStream_t);
+    // sources (staged: accumulate into dU)
+    void (*source)(const Geo&, const SourceArgs&, double dt, hipStream_t);
+    // dt limits: result combined into *out (bits of a positive double) with atomics
+    void (*max_speed)(const Geo&, const StatePhys&, const double* U, unsigned long long* out, hipStream_t);
+    void (*plasma_dt)(const Geo&, const SourceArgs&, unsigned long long* out, hipStream_t);
+    // ghosts
+    void (*fill_dim)(const Geo&, int nc, int ngs, double* A, int d, int side, FillRules, hipStream_t);
+    void (*pack)(const Geo&, int nc, int ngs, double* A, int d, int side, double* buf, int unpack, hipStream_t);
+    // fused paths (return 0 when the option set is not covered)
+    int (*ctu_fused)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
+                     const int touches[3][2], int* err, hipStream_t);
+    int (*source_fused)(const Geo&, const SourceArgs&, double dt, hipStream_t);
+    // batched leaves
+    int (*leaf_reconstruct)(int recon, long n, const double* st, double* slope, double* lo, double* hi, hipStream_t);
+    int (*leaf_riemann)(int flux, long n, const double* L, const double* R, double* F, double c0, double ch,
+                        double thr, hipStream_t);
+    int (*leaf_cons2prim)(long n, double mass, double gamma, const double* U, double* Q, double* sp, hipStream_t);
+    int (*leaf_prim2cons)(long n, double mass, double gamma, const double* Q, double* U, hipStream_t);
+};
+
+}  // namespace cmfp
+
+namespace strict {
+const cmfp::Launchers* launchers();
+}
+namespace fast {
+const cmfp::Launchers* launchers();
+}

@@ -1,0 +1,237 @@
+"""Host-side level driver over the C ABI: the role of `MFP : AmrLevel` plus the
+`Amr::coarseTimeStep` loop (Source/MFP.H:27-255, MFP_advance.cpp,
+MFP_timestep.cpp, main.cpp:154-162) for one uniform level.
+
+One process per GPU.  With world_size > 1 the index space is cut into a
+Cartesian grid of blocks (one per rank); ghost faces travel between ranks as
+packed device buffers through torch.distributed point-to-point ops (RCCL on
+GPU, gloo in the CPU tests of the exchange logic) and dt is min-reduced.  torch
+is used for device buffers, streams and the process group only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, lib
+from .config import Problem
+
+
+def block_grid(dim, world):
+    """Cartesian process grid: 2-D -> 1x2, 2x2, 2x4; 3-D -> 1x1x2, 1x2x2, 2x2x2
+    (SURVEY.md §8e).  The last dimension is split first."""
+    grid = [1, 1, 1]
+    d = dim - 1
+    w = world
+    while w > 1:
+        if w % 2:
+            raise ValueError("world size must be a power of two")
+        grid[d] *= 2
+        w //= 2
+        d = d - 1 if d > 0 else dim - 1
+    return grid
+
+
+def rank_coords(rank, grid):
+    return [rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1])]
+
+
+def coords_rank(c, grid):
+    return c[0] + grid[0] * (c[1] + grid[1] * c[2])
+
+
+class MFP:
+    def __init__(self, problem, device=0, rank=0, world=1, stream=0, fused=True, pg=None, exchange_device=None):
+        self.L = lib.load()
+        self.p = problem if isinstance(problem, Problem) else Problem(problem)
+        p = self.p
+        self.rank, self.world, self.pg = rank, world, pg
+        self.grid = block_grid(p.dim, world)
+        self.coords = rank_coords(rank, self.grid)
+        self.block_n, self.block_lo = [1, 1, 1], [0, 0, 0]
+        for d in range(3):
+            if p.n_cell[d] % self.grid[d]:
+                raise ValueError("n_cell must be divisible by the process grid")
+            self.block_n[d] = p.n_cell[d] // self.grid[d]
+            self.block_lo[d] = self.coords[d] * self.block_n[d]
+        self._geom = p.geometry(self.block_lo, self.block_n)
+        self._params = p.params()
+        self._sd, self._ad = p.state_descs(), p.action_descs()
+        self.n_states, self.n_actions = len(p.state_names), len(p.action_names)
+        h = C.c_void_p()
+        rc = self.L.cmfp_create(C.byref(self._geom), C.byref(self._params), self.n_states, self._sd, self.n_actions,
+                                self._ad, device, C.c_void_p(stream), C.byref(h))
+        self.h = h
+        if rc:
+            msg = self.L.cmfp_last_error(h).decode() if h else "no context"
+            if rc == abi.ERR_NODEVICE:
+                msg = "no HIP device visible: the hyperbolic update has no CPU fallback"
+            raise lib.CmfpError(rc, msg)
+        self.L.cmfp_set_fused(self.h, int(fused))
+        self.shape = tuple(self.block_n[::-1])
+        self.time, self.dt, self.step = 0.0, None, 0
+        self._cb = None
+        self._bufs = {}
+        self._exchange_device = exchange_device
+        if world > 1:
+            self._cb = lib.EXCHANGE_FN(self._exchange)
+            self._chk(self.L.cmfp_set_exchange_callback(self.h, self._cb, None))
+
+    # ------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc:
+            raise lib.CmfpError(rc, self.L.cmfp_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cmfp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data -------------------------------------------------------------
+    def init_data(self):
+        """MFP::initData (MFP.cpp:156): evaluate the initial conditions on this block."""
+        for s in range(self.n_states):
+            self.upload(s, self.p.initial_data(s, self.block_lo, self.block_n))
+
+    def upload(self, s, data):
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        assert data.shape == (self.p.n_comp(s),) + self.shape, (data.shape, self.shape)
+        self._chk(self.L.cmfp_state_upload(self.h, s, data.ctypes.data_as(lib.dp)))
+
+    def download(self, s):
+        out = np.empty((self.p.n_comp(s),) + self.shape)
+        self._chk(self.L.cmfp_state_download(self.h, s, out.ctypes.data_as(lib.dp)))
+        return out
+
+    def update_download(self, s, which):
+        out = np.empty((self.p.n_comp(s),) + self.shape)
+        self._chk(self.L.cmfp_update_download(self.h, s, which, out.ctypes.data_as(lib.dp)))
+        return out
+
+    def device_view(self, s):
+        ptr, ng, ext, nc = C.c_void_p(), C.c_int(), (C.c_longlong * 3)(), C.c_int()
+        self._chk(self.L.cmfp_state_device_view(self.h, s, C.byref(ptr), C.byref(ng), C.byref(ext), C.byref(nc)))
+        return ptr.value, ng.value, list(ext), nc.value
+
+    # -- stepping ---------------------------------------------------------
+    def advance(self, dt):
+        self._chk(self.L.cmfp_advance(self.h, self.time, dt))
+        self.time += dt
+        self.step += 1
+
+    def est_time_step(self):
+        """MFP::estTimeStep incl. ParallelDescriptor::ReduceRealMin (MFP_timestep.cpp:4-21)."""
+        v = C.c_double()
+        self._chk(self.L.cmfp_est_time_step(self.h, C.byref(v)))
+        dt = v.value
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device=self._comm_device())
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.pg)
+            dt = float(t.item())
+        return dt
+
+    def state_allowed_dt(self, s):
+        v = C.c_double()
+        self._chk(self.L.cmfp_state_get_allowed_time_step(self.h, s, C.byref(v)))
+        return v.value
+
+    def action_allowed_dt(self, a):
+        v = C.c_double()
+        self._chk(self.L.cmfp_action_get_allowed_time_step(self.h, a, C.byref(v)))
+        return v.value
+
+    def run(self, nsteps, dt0=None):
+        """computeInitialDt, then advance + computeNewDt (1.1x cap) per step
+        (MFP_timestep.cpp:23-119; no stop_time clip)."""
+        dts = []
+        if self.dt is None:
+            self.dt = self.est_time_step() if dt0 is None else dt0
+        for _ in range(nsteps):
+            self.advance(self.dt)
+            dts.append(self.dt)
+            self.dt = self.L.cmfp_compute_new_dt(self.est_time_step(), self.dt)
+        return dts
+
+    # -- Action API mirror (stage-level access for tests) ------------------
+    def update_begin(self):
+        self._chk(self.L.cmfp_update_begin(self.h))
+
+    def action_get_data(self, a):
+        self._chk(self.L.cmfp_action_get_data(self.h, a, self.time))
+
+    def action_calc_time_derivative(self, a, dt):
+        self._chk(self.L.cmfp_action_calc_time_derivative(self.h, a, self.time, dt))
+
+    def action_calc_spatial_derivative(self, a, dt):
+        self._chk(self.L.cmfp_action_calc_spatial_derivative(self.h, a, self.time, dt, dt))
+
+    def fill_patch(self, s):
+        self._chk(self.L.cmfp_fill_patch(self.h, s))
+
+    # -- halo exchange between ranks ----------------------------------------
+    def _comm_device(self):
+        import torch
+        if self._exchange_device is not None:
+            return self._exchange_device
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def neighbour(self, d, side):
+        """Rank owning the block next to face (d, side), or None at a physical boundary."""
+        c = list(self.coords)
+        c[d] += -1 if side == 0 else 1
+        if c[d] < 0 or c[d] >= self.grid[d]:
+            if not self.p.periodic[d]:
+                return None
+            c[d] %= self.grid[d]
+        return coords_rank(c, self.grid)
+
+    def _exchange(self, user, ctx, s, d):
+        """cmfp_exchange_fn: pack both faces, swap with the neighbours, unpack."""
+        try:
+            import torch
+            import torch.distributed as dist
+            n = int(self.L.cmfp_halo_count(self.h, s, d))
+            key = (s, d)
+            if key not in self._bufs:
+                dev = torch.device("cuda", torch.cuda.current_device())
+                self._bufs[key] = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(4)]
+            send_lo, send_hi, recv_lo, recv_hi = self._bufs[key]
+            nb_lo, nb_hi = self.neighbour(d, 0), self.neighbour(d, 1)
+            ops = []
+            if nb_lo is not None:
+                self._chk(self.L.cmfp_halo_pack(self.h, s, d, 0, C.c_void_p(send_lo.data_ptr())))
+            if nb_hi is not None:
+                self._chk(self.L.cmfp_halo_pack(self.h, s, d, 1, C.c_void_p(send_hi.data_ptr())))
+            if nb_lo is not None:
+                ops.append(dist.P2POp(dist.isend, send_lo, nb_lo, group=self.pg))
+                ops.append(dist.P2POp(dist.irecv, recv_lo, nb_lo, group=self.pg))
+            if nb_hi is not None:
+                ops.append(dist.P2POp(dist.isend, send_hi, nb_hi, group=self.pg))
+                ops.append(dist.P2POp(dist.irecv, recv_hi, nb_hi, group=self.pg))
+            if ops:
+                if nb_lo == nb_hi and nb_lo is not None:
+                    # two ranks along a periodic dimension: both messages go to the same
+                    # peer; order the recvs to match the peer's sends (its hi face is my lo ghost)
+                    ops = [dist.P2POp(dist.isend, send_lo, nb_lo, group=self.pg),
+                           dist.P2POp(dist.isend, send_hi, nb_hi, group=self.pg),
+                           dist.P2POp(dist.irecv, recv_hi, nb_hi, group=self.pg),
+                           dist.P2POp(dist.irecv, recv_lo, nb_lo, group=self.pg)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            if nb_lo is not None:
+                self._chk(self.L.cmfp_halo_unpack(self.h, s, d, 0, C.c_void_p(recv_lo.data_ptr())))
+            if nb_hi is not None:
+                self._chk(self.L.cmfp_halo_unpack(self.h, s, d, 1, C.c_void_p(recv_hi.data_ptr())))
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            self._exchange_error = e
+            return 1
