@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the hyperbolic update (BASELINE.json metric: cell-updates/s,
+fp64, five-moment two-fluid + Maxwell; % of HBM roofline).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run).
+A "step" is one full time step of the whole level: Strang source half step,
+ghost fill, CTU flux update of every state, source half step, CFL dt estimate
+(with the cross-rank min) — on synthetic analytic initial data already resident
+in HBM.  Weak scaling: every GPU owns an n x n block.  Rank 0 prints one JSON
+line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES = {"ot2f_2d": 320, "kh_2d": 80}   # 2 x 8 B x Ncomp per cell-update
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_problem(workload, n, grid, fp_mode):
+    from cerberus_amd import config, problems
+    if workload == "ot2f_2d":
+        cfg = problems.orszag_tang_two_fluid_2d(n)
+    elif workload == "kh_2d":
+        cfg = problems.kelvin_helmholtz_2d(n)
+    else:
+        raise SystemExit(f"unknown workload {workload}")
+    # weak scaling: the domain grows with the process grid, dx and the per-GPU block stay fixed
+    # (both initial conditions are periodic with the single-GPU domain length)
+    for d in range(2):
+        L = cfg["prob_hi"][d] - cfg["prob_lo"][d]
+        cfg["n_cell"][d] = n * grid[d]
+        cfg["prob_hi"][d] = cfg["prob_lo"][d] + L * grid[d]
+    return config.Problem(cfg, fp_mode=fp_mode)
+
+
+def cpu_baseline(workload, seconds=12.0):
+    """The CPU restatement (oracle/, kind 'port') timed on this host's cores on a
+    bounded sample of the same workload: 384^2 cells in 32^2 boxes (the
+    reference's amr.max_grid_size in its shipped inputs), whole steps until
+    `seconds` of wall time have been spent."""
+    from oracle import oracle as O
+    from cerberus_amd import abi
+    n = 384
+    P = build_problem(workload, n, [1, 1, 1], abi.FP_STRICT)
+    threads = max(1, min(16, os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    O.lib().orc_set_threads(threads)
+    sim = O.OracleSim(P, max_grid_size=32)
+    dt = sim.est_time_step()
+    sim.advance(dt)          # untimed first step (page faults, allocations)
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 200:
+        dt = min(sim.est_time_step(), 1.1 * dt)
+        sim.advance(dt)
+        steps += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    el = time.perf_counter() - t0
+    return {"value": n * n * steps / el, "unit": "cell-updates/s", "cores": threads, "kind": "port",
+            "sample": f"{workload} {n}x{n}, max_grid_size 32, {steps} steps, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ot2f_2d", choices=sorted(ALGO_BYTES))
+    ap.add_argument("--n", type=int, default=4096, help="cells per side of the per-GPU block")
+    ap.add_argument("--fp", default="fast", choices=["fast", "strict"])
+    ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cerberus_amd import abi
+    from cerberus_amd.mfp import MFP, block_grid
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hyperbolic update has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    fp_mode = abi.FP_FAST if args.fp == "fast" else abi.FP_STRICT
+    grid = block_grid(2, world)
+    P = build_problem(args.workload, args.n, grid, fp_mode)
+    m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=not args.no_fused)
+    m.init_data()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    m.run(args.warmup)
+    fused = m.last_advance_fused()
+    sync()
+    m.profile_enable(True)
+    for s in range(4):
+        m.profile_read(s)
+    t0 = time.perf_counter()
+    m.run(args.steps)
+    sync()
+    el = time.perf_counter() - t0
+    prof = [m.profile_read(s) for s in range(4)]
+    m.profile_enable(False)
+
+    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+
+    cells_per_gpu = args.n * args.n
+    total_cells = cells_per_gpu * world
+    value = total_cells * args.steps / el
+
+    out = None
+    if rank == 0:
+        # dominant kernel: the fused CTU update of one hydro state (5 comps -> 80 B per cell)
+        launches, ms = prof[0]
+        roof = None
+        if launches:
+            avg_s = ms / launches * 1e-3
+            algo = 80.0 * cells_per_gpu
+            achieved = algo / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                key = f"{args.workload}:{args.n}"
+                if tj.get(key):
+                    traffic = tj[key]["ctu_hydro_bytes_per_launch"]
+            roof = {"bound": "hbm", "kernel": "k_ctu2d<HydroF<minmod,HLLC>> (fused CTU update of one hydro state)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms / launches,
+                    "launches": launches}
+        step_bytes = ALGO_BYTES[args.workload] * cells_per_gpu
+        out = {
+            "metric": "cell-updates/s (fp64, five-moment 2-fluid+Maxwell)" if args.workload == "ot2f_2d"
+                      else "cell-updates/s (fp64, single-fluid hydro)",
+            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {args.n}x{args.n} per GPU "
+                                   f"({'BASELINE configs[2]: 2D two-fluid Orszag-Tang, plasma5 source' if args.workload == 'ot2f_2d' else 'BASELINE configs[1]: 2D KH hydro HLLC'})",
+                       "process_grid": grid[:2], "global_cells": [P.n_cell[0], P.n_cell[1]], "fp_mode": args.fp,
+                       "fused_kernels": bool(fused), "time_integration": P.scheme, "cfl": P.cfl},
+            "hbm_roofline_frac_whole_step": (step_bytes * args.steps / (el)) / 1e9 / HBM_PEAK_GBS,
+            "roofline": roof,
+            "kernel_ms_per_step": {"ctu_hydro": prof[0][1] / args.steps, "ctu_field": prof[1][1] / args.steps,
+                                   "source_rk2": prof[2][1] / args.steps, "ghost_fill": prof[3][1] / args.steps},
+        }
+    m.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,10 @@ struct cmfp_context {
     int* d_err = nullptr;
     unsigned long long* d_red = nullptr;  // one reduction word per state + per action
     std::string err;
+    int last_fused = 0;
+    int profiling = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[CMFP_PROF_NSLOTS];
+    std::vector<hipEvent_t> ev_pool;
     std::vector<double*> allocs;
     std::vector<double> staging;
 };
@@ -91,6 +95,34 @@ int fail(cmfp_context* c, int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                        \
             return fail(c, CMFP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
     } while (0)
+
+// event pair around a kernel launch while profiling is enabled
+struct ProfScope {
+    cmfp_context* c;
+    int slot;
+    hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t get(cmfp_context* c) {
+        hipEvent_t e = nullptr;
+        if (!c->ev_pool.empty()) {
+            e = c->ev_pool.back();
+            c->ev_pool.pop_back();
+        } else if (hipEventCreate(&e) != hipSuccess) {
+            e = nullptr;
+        }
+        return e;
+    }
+    ProfScope(cmfp_context* ctx, int s) : c(ctx), slot(s) {
+        if (!c->profiling) return;
+        a = get(c);
+        b = get(c);
+        if (a) (void)hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (!a || !b) return;
+        (void)hipEventRecord(b, c->stream);
+        c->prof[slot].push_back({a, b});
+    }
+};
 
 int dalloc(cmfp_context* c, double** p, long n) {
     if (*p) return CMFP_OK;
@@ -142,6 +174,7 @@ FillRules wrap_rules(const StateRT& s) {
 int fill_patch(cmfp_context* c, int si) {
     StateRT& s = c->states[si];
     const Geo& g = c->g;
+    ProfScope prof(c, CMFP_PROF_FILL);
     for (int d = 0; d < g.dim; ++d) {
         if (!c->split[d]) {
             for (int side = 0; side < 2; ++side) {
@@ -407,6 +440,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
                     return 0;
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
+        ProfScope prof(c, CMFP_PROF_SOURCE);
         if (!c->L->source_fused(c->g, a, 0.5 * dt, c->stream)) return 0;
     }
     for (const auto& A : c->actions) {
@@ -416,12 +450,16 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             int r;
             if ((r = dalloc(c, &s.alt, s.sp.nc * c->g.sc))) return r;
             if ((r = fill_patch(c, A.states[i]))) return r;
-            c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, A.corner_transport, dt, c->touches, c->d_err, c->stream);
+            {
+                ProfScope prof(c, s.sp.kind == CMFP_STATE_HYDRO ? CMFP_PROF_CTU_HYDRO : CMFP_PROF_CTU_FIELD);
+                c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, A.corner_transport, dt, c->touches, c->d_err, c->stream);
+            }
             std::swap(s.new_data, s.alt);
         }
     }
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
+        ProfScope prof(c, CMFP_PROF_SOURCE);
         c->L->source_fused(c->g, a, 0.5 * dt, c->stream);
     }
     return 1;
@@ -550,6 +588,12 @@ int cmfp_destroy(cmfp_context* c) {
     if (!c) return CMFP_ERR_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (int s = 0; s < CMFP_PROF_NSLOTS; ++s)
+        for (auto& pr : c->prof[s]) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (double* p : c->allocs) (void)hipFree(p);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_red) (void)hipFree(c->d_red);
@@ -769,16 +813,46 @@ int cmfp_set_fused(cmfp_context* c, int enable) {
 int cmfp_advance(cmfp_context* c, double, double dt) {
     int r;
     if ((r = check_ctx(c))) return r;
+    c->last_fused = 0;
     if (c->fused) {
         r = advance_strang_fused(c, dt);
         if (r < 0) return r;
-        if (r == 1) return CMFP_OK;
+        if (r == 1) {
+            c->last_fused = 1;
+            return CMFP_OK;
+        }
     }
     for (auto& s : c->states)
         if ((r = ensure_update(c, s))) return r;
     swap_levels(c);
     if (c->params.time_integrator == CMFP_TI_STRANG) return advance_strang(c, dt);
     return advance_RK(c, dt);
+}
+
+int cmfp_last_advance_fused(const cmfp_context* c) { return c ? c->last_fused : 0; }
+
+int cmfp_profile_enable(cmfp_context* c, int on) {
+    if (!c) return CMFP_ERR_INVALID;
+    c->profiling = on;
+    return CMFP_OK;
+}
+int cmfp_profile_read(cmfp_context* c, int slot, long long* launches, double* total_ms) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (slot < 0 || slot >= CMFP_PROF_NSLOTS || !launches || !total_ms) return fail(c, CMFP_ERR_INVALID, "bad profile slot");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double ms = 0;
+    for (auto& pr : c->prof[slot]) {
+        float t = 0;
+        HIPCHK(c, hipEventElapsedTime(&t, pr.first, pr.second));
+        ms += t;
+        c->ev_pool.push_back(pr.first);
+        c->ev_pool.push_back(pr.second);
+    }
+    *launches = (long long)c->prof[slot].size();
+    *total_ms = ms;
+    c->prof[slot].clear();
+    return CMFP_OK;
 }
 
 int cmfp_set_exchange_callback(cmfp_context* c, cmfp_exchange_fn fn, void* user) {

@@ -1,10 +1,305 @@
-// mfp_fused.hip — hand-fused CTU update kernels (filled in below the staged path).
+// mfp_fused.hip — hand-fused corner-transport-upwind update for gfx950.
+//
+// One launch does, for one state on one 2-D block, everything
+// HydroCTU::calc_spatial_derivative (MFP_CTU_hydro.cpp:142-531) does with eight
+// separate full-array passes, plus the `new += dU` of the integrator
+// (MFP_advance.cpp:220-230):
+//
+//   U -> primitives -> slope-limited faces -> half-step trace -> Riemann sweep 1
+//     -> transverse correction -> domain-face BCs -> Riemann sweep 2 -> divergence
+//
+// Each conserved component is read from HBM once (plus the tile halo, served by
+// L2) and written once.  A workgroup owns a (BX-2) x (BY-2) tile of cells and
+// runs one thread per cell of the tile grown by one (the cells whose face states
+// the tile consumes).  Face states stay in registers; only what a neighbouring
+// cell needs (the high-side face states and the face fluxes) is exchanged
+// through LDS, in five barrier-separated phases.  Arithmetic per value is the
+// same sequence of operations as the staged kernels (same device functions), so
+// results are identical to them bit for bit.
 #include "mfp_device.h"
 
 namespace CMFP_NS {
 using namespace cmfp;
 
-int ctu_fused(const Geo&, const StatePhys&, const double*, double*, int, double, const int[3][2], int*, hipStream_t) {
+struct FaceBC {
+    int touch[2][2];   // [d][side]: physical (non-periodic) domain face on this block
+    int rule[2][2][10];  // FILL_SKIP / FILL_EVEN / FILL_ODD per primitive comp
+};
+
+template <class Phys, int BX, int BY>
+__global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
+                                                   double* __restrict__ Uout, int do_ctu, double dt, FaceBC bc, int* err) {
+    constexpr int NQ = Phys::NQ, NC = Phys::NC, NF = Phys::NF, RECON = Phys::RECON;
+    constexpr int SL = ReconTraits<RECON>::SL, H = SL / 2;
+    constexpr int TX = BX - 2, TY = BY - 2;
+    constexpr int PX = BX + 2 * H, PY = BY + 2 * H;
+    constexpr int C = BX * BY;
+    constexpr int NA = (NQ * PX * PY > 2 * NF * C) ? NQ * PX * PY : 2 * NF * C;
+    __shared__ double bufA[NA];          // phase 0-1: primitives; phase 2-5: face fluxes
+    __shared__ double bufR[2 * NQ * C];  // high-side face states of every cell, both directions
+    double* const Pq = bufA;
+    double* const Fb = bufA;
+
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * BX + tx;
+    const int i0 = blockIdx.x * TX, j0 = blockIdx.y * TY;
+    const int i = i0 - 1 + tx, j = j0 - 1 + ty;  // this thread's cell
+    const int n0 = g.n[0], n1 = g.n[1];
+    const double gm1 = Phys::IS_HYDRO ? Phys::gamma_of(P) - 1.0 : 0.0;
+
+    // ---- phase 0: conserved -> primitives for the tile grown by 1 + H
+    for (int t = tid; t < PX * PY; t += C) {
+        const int px = t % PX, py = t / PX;
+        const int ci = i0 - 1 - H + px, cj = j0 - 1 - H + py;
+        if (ci >= -(1 + H) && ci <= n0 + H && cj >= -(1 + H) && cj <= n1 + H) {
+            const long c = g.at(ci, cj, 0);
+            double U[NC], Q[NQ];
+#pragma unroll
+            for (int n = 0; n < NC; ++n) U[n] = Uin[c + n * g.sc];
+            if (!Phys::cons2prim(P, U, Q)) *err = 1;
+            if (Phys::IS_HYDRO) Q[H_P] = Q[H_P] / gm1;  // eps = p / (gamma - 1), MFP_hydro.cpp:847-862
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) Pq[n * (PX * PY) + t] = Q[n];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: reconstruction + half-step trace of this cell, both directions
+    double lo[2][NQ], hi[2][NQ];
+    {
+        const int pc = (ty + H) * PX + (tx + H);
+        double centre[NQ], speed[3];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) centre[n] = Pq[n * (PX * PY) + pc];
+        if (Phys::IS_HYDRO) centre[H_P] = centre[H_P] * gm1;  // restored pressure, MFP_hydro.cpp:1025-1035
+        Phys::speed_from_prim(P, centre, speed);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int sd = d == 0 ? 1 : PX;
+            if constexpr (Phys::IS_HYDRO) {
+                double st[SL][5];
+#pragma unroll
+                for (int s = 0; s < SL; ++s)
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) st[s][n] = Pq[n * (PX * PY) + pc + (s - H) * sd];
+                hydro_cell_faces<RECON>(Phys::gamma_of(P), st, lo[d], hi[d]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    double st[SL];
+#pragma unroll
+                    for (int s = 0; s < SL; ++s) st[s] = Pq[n * (PX * PY) + pc + (s - H) * sd];
+                    recon_faces<RECON>(st, lo[d][n], hi[d][n]);
+                }
+            }
+            if (do_ctu) {
+                const double dt_2dx = 0.5 * dt / g.dx[d];
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) trace_faces(speed[d], dt_2dx, centre[n], lo[d][n], hi[d][n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) bufR[(d * NQ + n) * C + tid] = hi[d][n];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: Riemann sweep 1 on the low faces of this cell
+    double fx[NC] = {0}, fy[NC] = {0};
+    {
+        double L[NQ];
+        if (tx >= 1) {
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) L[n] = bufR[(0 * NQ + n) * C + tid - 1];
+            Phys::riemann(P, 0, L, lo[0], fx);
+        }
+        if (ty >= 1) {
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) L[n] = bufR[(1 * NQ + n) * C + tid - BX];
+            Phys::riemann(P, 1, L, lo[1], fy);
+        }
+    }
+    if (do_ctu) {
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            Fb[(0 * NF + n) * C + tid] = fx[n];
+            Fb[(1 * NF + n) * C + tid] = fy[n];
+        }
+        __syncthreads();
+
+        // ---- phase 3: transverse correction of this cell's face states
+        // (EulerianState::correct_face_prim MFP_eulerian.cpp:1047-1188, written per cell:
+        //  each face state is corrected with the transverse fluxes of its own cell)
+        const bool row_in = (ty >= 1 && ty <= BY - 2 && j < n1);   // cell row inside the block
+        const bool col_in = (tx >= 1 && tx <= BX - 2 && i < n0);
+        if (row_in) {
+            // x-face states use F_y(i,j) - F_y(i,j+1)
+            double dF[NF];
+            const double k = 0.5 * dt / g.dx[1];
+#pragma unroll
+            for (int n = 0; n < NF; ++n) dF[n] = fy[n] - Fb[(1 * NF + n) * C + tid + BX];
+            if (tx <= BX - 2 && i < n0) {
+                if (!Phys::correct(P, hi[0], k, dF)) *err = 1;
+            }
+            if (tx >= 1 && i <= n0) {
+                if (!Phys::correct(P, lo[0], k, dF)) *err = 1;
+            }
+        }
+        if (col_in) {
+            double dF[NF];
+            const double k = 0.5 * dt / g.dx[0];
+#pragma unroll
+            for (int n = 0; n < NF; ++n) dF[n] = fx[n] - Fb[(0 * NF + n) * C + tid + 1];
+            if (ty <= BY - 2 && j < n1) {
+                if (!Phys::correct(P, hi[1], k, dF)) *err = 1;
+            }
+            if (ty >= 1 && j <= n1) {
+                if (!Phys::correct(P, lo[1], k, dF)) *err = 1;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) bufR[(d * NQ + n) * C + tid] = hi[d][n];
+        __syncthreads();
+
+        // ---- phase 4: domain-face BCs (update_face_prim, do_all) + Riemann sweep 2
+        {
+            double L[NQ], R[NQ];
+            if (tx >= 1) {
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    L[n] = bufR[(0 * NQ + n) * C + tid - 1];
+                    R[n] = lo[0][n];
+                }
+                if (bc.touch[0][0] && i == 0) {
+#pragma unroll
+                    for (int n = 0; n < NQ; ++n)
+                        if (bc.rule[0][0][n]) L[n] = bc.rule[0][0][n] == FILL_ODD ? -R[n] : R[n];
+                }
+                if (bc.touch[0][1] && i == n0) {
+#pragma unroll
+                    for (int n = 0; n < NQ; ++n)
+                        if (bc.rule[0][1][n]) R[n] = bc.rule[0][1][n] == FILL_ODD ? -L[n] : L[n];
+                }
+                Phys::riemann(P, 0, L, R, fx);
+            }
+            if (ty >= 1) {
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    L[n] = bufR[(1 * NQ + n) * C + tid - BX];
+                    R[n] = lo[1][n];
+                }
+                if (bc.touch[1][0] && j == 0) {
+#pragma unroll
+                    for (int n = 0; n < NQ; ++n)
+                        if (bc.rule[1][0][n]) L[n] = bc.rule[1][0][n] == FILL_ODD ? -R[n] : R[n];
+                }
+                if (bc.touch[1][1] && j == n1) {
+#pragma unroll
+                    for (int n = 0; n < NQ; ++n)
+                        if (bc.rule[1][1][n]) R[n] = bc.rule[1][1][n] == FILL_ODD ? -L[n] : L[n];
+                }
+                Phys::riemann(P, 1, L, R, fy);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+        Fb[(0 * NF + n) * C + tid] = fx[n];
+        Fb[(1 * NF + n) * C + tid] = fy[n];
+    }
+    __syncthreads();
+
+    // ---- phase 5: divergence (calc_divergence MFP_eulerian.cpp:1614-1662) and new += dU
+    if (tx >= 1 && tx <= BX - 2 && ty >= 1 && ty <= BY - 2 && i < n0 && j < n1) {
+        const long c = g.at(i, j, 0);
+        const double dtdx = dt / g.dx[0], dtdy = dt / g.dx[1];
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            double du = 0.0;
+            if (n < NF) {
+                du += dtdx * (fx[n] - Fb[(0 * NF + n) * C + tid + 1]);
+                du += dtdy * (fy[n] - Fb[(1 * NF + n) * C + tid + BX]);
+            } else {
+                du += dtdx * (0.0 - 0.0);
+                du += dtdy * (0.0 - 0.0);
+            }
+            Uout[c + n * g.sc] = Uin[c + n * g.sc] + du;
+        }
+    }
+}
+
+// physics adaptors used by the fused kernel (the staged kernels use the same
+// device functions through HydroPhys / FieldPhys of mfp_device.h)
+template <int RECON_, int FLUX_> struct HydroF : HydroPhys<RECON_, FLUX_> {
+    typedef HydroParams Params;
+    static CMFP_DEV double gamma_of(const Params& P) { return P.gas.gamma; }
+    // prim -> cons, += k * dF, cons -> prim  (MFP_eulerian.cpp:1132-1176)
+    static CMFP_DEV bool correct(const Params& P, double* Q, double k, const double* dF) {
+        double U[5];
+        hydro_prim2cons(P.gas, Q, U);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) U[n] += k * dF[n];
+        return hydro_cons2prim(P.gas, U, Q);
+    }
+};
+template <int RECON_> struct FieldF : FieldPhys<RECON_> {
+    typedef FieldParams Params;
+    static CMFP_DEV double gamma_of(const Params&) { return 0.0; }
+    static CMFP_DEV bool correct(const Params&, double* Q, double k, const double* dF) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) Q[n] += k * dF[n];
+        return true;
+    }
+};
+
+static FaceBC make_bc(const StatePhys& sp, const int touches[3][2]) {
+    FaceBC b;
+    for (int d = 0; d < 2; ++d)
+        for (int s = 0; s < 2; ++s) {
+            b.touch[d][s] = touches[d][s];
+            for (int n = 0; n < 10; ++n) {
+                int code = (n < sp.nc) ? sp.bc[n][d][s] : -666;  // MFP_eulerian.cpp:796-835
+                b.rule[d][s][n] = (code == 2 || code == 4 || code == 1) ? FILL_EVEN : (code == -1 ? FILL_ODD : FILL_SKIP);
+            }
+        }
+    return b;
+}
+
+template <class Phys, int BX, int BY>
+static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhys& sp, const double* Uin, double* Uout,
+                    int do_ctu, double dt, const int touches[3][2], int* err, hipStream_t st) {
+    if (!Uin) return 1;  // coverage probe
+    dim3 grid((g.n[0] + BX - 3) / (BX - 2), (g.n[1] + BY - 3) / (BY - 2));
+    hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY>), grid, dim3(BX, BY), 0, st, g, P, Uin, Uout, do_ctu, dt,
+                       make_bc(sp, touches), err);
+    return 1;
+}
+
+#ifndef CMFP_HBX
+#define CMFP_HBX 16
+#define CMFP_HBY 16
+#endif
+#ifndef CMFP_FBX
+#define CMFP_FBX 16
+#define CMFP_FBY 16
+#endif
+
+int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
+              const int touches[3][2], int* err, hipStream_t st) {
+    if (g.dim != 2) return 0;
+#define HY(R, F)                                                                                                    \
+    if (sp.recon == R && sp.flux == F)                                                                              \
+        return launch2d<HydroF<R, F>, CMFP_HBX, CMFP_HBY>(g, sp.hp, sp, Uin, Uout, do_ctu, dt, touches, err, st);
+#define FI(R)                                                                                                       \
+    if (sp.recon == R) return launch2d<FieldF<R>, CMFP_FBX, CMFP_FBY>(g, sp.fp, sp, Uin, Uout, do_ctu, dt, touches, err, st);
+    if (sp.kind == 0) {
+        HY(1, 0) HY(1, 1) HY(1, 2) HY(2, 0) HY(2, 1) HY(2, 2) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)
+    } else {
+        FI(5) FI(1) FI(2) FI(6)
+    }
+#undef HY
+#undef FI
     return 0;
 }
 

@@ -37,6 +37,9 @@ SYMBOLS = [
     ("cmfp_compute_new_dt", C.c_double, [C.c_double, C.c_double]),
     ("cmfp_advance", C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     ("cmfp_set_fused", C.c_int, [C.c_void_p, C.c_int]),
+    ("cmfp_last_advance_fused", C.c_int, [C.c_void_p]),
+    ("cmfp_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("cmfp_profile_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), dp]),
     ("cmfp_set_exchange_callback", C.c_int, [C.c_void_p, EXCHANGE_FN, C.c_void_p]),
     ("cmfp_fill_patch", C.c_int, [C.c_void_p, C.c_int]),
     ("cmfp_halo_count", C.c_longlong, [C.c_void_p, C.c_int, C.c_int]),

@@ -159,6 +159,17 @@ class MFP:
             self.dt = self.L.cmfp_compute_new_dt(self.est_time_step(), self.dt)
         return dts
 
+    def last_advance_fused(self):
+        return bool(self.L.cmfp_last_advance_fused(self.h))
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.cmfp_profile_enable(self.h, int(on)))
+
+    def profile_read(self, slot):
+        n, ms = C.c_longlong(), C.c_double()
+        self._chk(self.L.cmfp_profile_read(self.h, slot, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     # -- Action API mirror (stage-level access for tests) ------------------
     def update_begin(self):
         self._chk(self.L.cmfp_update_begin(self.h))

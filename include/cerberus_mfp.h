@@ -212,6 +212,25 @@ int cmfp_advance(cmfp_context* ctx, double time, double dt);
  * functions one to one.  Results are identical. */
 int cmfp_set_fused(cmfp_context* ctx, int enable);
 
+/* 1 if the last cmfp_advance ran through the hand-fused kernels, 0 if it took
+ * the stage-by-stage kernels. */
+int cmfp_last_advance_fused(const cmfp_context* ctx);
+
+/* Per-kernel device timing: HIP events recorded on the context's stream around
+ * every launch of the fused kernels while enabled (the reference's nearest
+ * analogue is its per-box wall-time cost, MFP_CTU_hydro.cpp:143,529-530).
+ * cmfp_profile_read synchronises, returns launches and summed milliseconds of
+ * one slot since the last read, and resets the slot. */
+typedef enum {
+    CMFP_PROF_CTU_HYDRO = 0,
+    CMFP_PROF_CTU_FIELD = 1,
+    CMFP_PROF_SOURCE = 2,
+    CMFP_PROF_FILL = 3,
+    CMFP_PROF_NSLOTS = 4
+} cmfp_prof_slot;
+int cmfp_profile_enable(cmfp_context* ctx, int on);
+int cmfp_profile_read(cmfp_context* ctx, int slot, long long* launches, double* total_ms);
+
 /* ---- Ghost cells: the FillPatch of Action::get_data (MFP_action.cpp:59) ->
  * FillBC::operator() -> fab_filcc (modules/boundary/MFP_fillbc.cpp:147-172).
  * Dimension d of the new-time data of `state` is filled over the full extent
