@@ -74,6 +74,8 @@ struct cmfp_context {
     void* exchange_user = nullptr;
     int* d_err = nullptr;
     unsigned long long* d_red = nullptr;  // one reduction word per state + per action
+    double* d_part = nullptr;             // CMFP_RED_BLOCKS block partials per word
+    std::vector<char> red_valid;          // word already holds the reduction of the current new-time data
     std::string err;
     int last_fused = 0;
     int profiling = 0;
@@ -214,6 +216,16 @@ SourceArgs source_args(cmfp_context* c, const cmfp_action_desc& A, bool on_new) 
     a.div_damp = f.desc.div_damping;
     a.lorentz_only = A.kind == CMFP_ACTION_LORENTZ;
     a.implicit = (A.kind == CMFP_ACTION_PLASMA5 && A.solver == CMFP_SOLVER_IMPLICIT);
+    a.limits_dt = (A.kind == CMFP_ACTION_PLASMA5 && A.solver == CMFP_SOLVER_EXPLICIT);  // MFP_plasma5.cpp:461
+    const int ai = (int)(&A - c->actions.data());
+    const int ns = (int)c->states.size();
+    for (int n = 0; n < a.n_species; ++n) {
+        a.gamma[n] = c->states[A.states[n]].desc.gamma;
+        a.part_speed[n] = c->d_part + (size_t)A.states[n] * CMFP_RED_BLOCKS;
+        a.out_speed[n] = c->d_red + A.states[n];
+    }
+    a.part_dt = c->d_part + (size_t)(ns + ai) * CMFP_RED_BLOCKS;
+    a.out_dt = c->d_red + ns + ai;
     return a;
 }
 
@@ -441,7 +453,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
         ProfScope prof(c, CMFP_PROF_SOURCE);
-        if (!c->L->source_fused(c->g, a, 0.5 * dt, c->stream)) return 0;
+        if (!c->L->source_fused(c->g, a, 0.5 * dt, 0, c->stream)) return 0;
     }
     for (const auto& A : c->actions) {
         if (A.kind != CMFP_ACTION_CTU) continue;
@@ -460,7 +472,11 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
         ProfScope prof(c, CMFP_PROF_SOURCE);
-        c->L->source_fused(c->g, a, 0.5 * dt, c->stream);
+        // last kernel of the step: it also leaves the CFL reductions of what it wrote
+        c->L->source_fused(c->g, a, 0.5 * dt, 1, c->stream);
+        const cmfp_action_desc& A = c->actions[src];
+        for (int n = 0; n < A.n_states - 1; ++n) c->red_valid[A.states[n]] = 1;
+        if (a.limits_dt) c->red_valid[c->states.size() + src] = 1;
     }
     return 1;
 }
@@ -580,6 +596,8 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     HIPCHK(c, hipMalloc((void**)&c->d_err, sizeof(int)));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
     HIPCHK(c, hipMalloc((void**)&c->d_red, sizeof(unsigned long long) * (n_states + n_actions + 1)));
+    HIPCHK(c, hipMalloc((void**)&c->d_part, sizeof(double) * (size_t)(n_states + n_actions + 1) * CMFP_RED_BLOCKS));
+    c->red_valid.assign(n_states + n_actions + 1, 0);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CMFP_OK;
 }
@@ -597,6 +615,7 @@ int cmfp_destroy(cmfp_context* c) {
     for (double* p : c->allocs) (void)hipFree(p);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_red) (void)hipFree(c->d_red);
+    if (c->d_part) (void)hipFree(c->d_part);
     delete c;
     return CMFP_OK;
 }
@@ -643,6 +662,7 @@ int cmfp_state_upload(cmfp_context* c, int s, const double* host) {
     int r;
     if ((r = check_ctx(c))) return r;
     if (s < 0 || s >= (int)c->states.size() || !host) return fail(c, CMFP_ERR_INVALID, "bad state index / pointer");
+    std::fill(c->red_valid.begin(), c->red_valid.end(), 0);
     return copy_state(c, c->states[s].new_data, c->states[s].sp.nc, const_cast<double*>(host), true);
 }
 int cmfp_state_download(cmfp_context* c, int s, double* host) {
@@ -715,8 +735,8 @@ static double as_double(unsigned long long b) {
 
 // launches the reduction for state s into word w; hydro only
 static int launch_state_dt(cmfp_context* c, int s, int w) {
-    HIPCHK(c, hipMemsetAsync(c->d_red + w, 0, sizeof(unsigned long long), c->stream));
-    c->L->max_speed(c->g, c->states[s].sp, c->states[s].new_data, c->d_red + w, c->stream);
+    c->L->max_speed(c->g, c->states[s].sp, c->states[s].new_data, c->d_part + (size_t)w * CMFP_RED_BLOCKS, c->d_red + w,
+                    c->stream);
     return CMFP_OK;
 }
 static double state_dt_from(const cmfp_context* c, int s, double max_speed) {
@@ -728,10 +748,8 @@ static double state_dt_from(const cmfp_context* c, int s, double max_speed) {
     return dt;
 }
 static int launch_action_dt(cmfp_context* c, int a, int w) {
-    // 0x7f7f...7f is a positive double (~1.4e306) above any time step: the identity of the min
-    HIPCHK(c, hipMemsetAsync(c->d_red + w, 0x7f, sizeof(unsigned long long), c->stream));
     SourceArgs sa = source_args(c, c->actions[a], true);
-    c->L->plasma_dt(c->g, sa, c->d_red + w, c->stream);
+    c->L->plasma_dt(c->g, sa, c->d_part + (size_t)w * CMFP_RED_BLOCKS, c->d_red + w, c->stream);
     return CMFP_OK;
 }
 static bool action_limits_dt(const cmfp_action_desc& A) {
@@ -752,12 +770,14 @@ int cmfp_state_get_allowed_time_step(cmfp_context* c, int s, double* dt) {
     int r;
     if ((r = check_ctx(c))) return r;
     if (s < 0 || s >= (int)c->states.size() || !dt) return fail(c, CMFP_ERR_INVALID, "bad state index / pointer");
-    std::vector<unsigned long long> h(1, 0);
+    const int nw = (int)(c->states.size() + c->actions.size());
+    std::vector<unsigned long long> h(nw, 0);
     if (c->states[s].sp.kind == CMFP_STATE_HYDRO) {
-        if ((r = launch_state_dt(c, s, 0))) return r;
+        if (!c->red_valid[s] && (r = launch_state_dt(c, s, s))) return r;
+        c->red_valid[s] = 1;
         if ((r = reduce_words(c, h))) return r;
     }
-    *dt = state_dt_from(c, s, as_double(h[0]));
+    *dt = state_dt_from(c, s, as_double(h[s]));
     return CMFP_OK;
 }
 int cmfp_action_get_allowed_time_step(cmfp_context* c, int a, double* dt) {
@@ -768,10 +788,12 @@ int cmfp_action_get_allowed_time_step(cmfp_context* c, int a, double* dt) {
         *dt = std::numeric_limits<double>::max();  // MFP_action.H:87, MFP_plasma5.cpp:461
         return CMFP_OK;
     }
-    std::vector<unsigned long long> h(1, 0);
-    if ((r = launch_action_dt(c, a, 0))) return r;
+    const int ns0 = (int)c->states.size();
+    std::vector<unsigned long long> h(ns0 + c->actions.size(), 0);
+    if (!c->red_valid[ns0 + a] && (r = launch_action_dt(c, a, ns0 + a))) return r;
+    c->red_valid[ns0 + a] = 1;
     if ((r = reduce_words(c, h))) return r;
-    *dt = action_dt_from(c, a, as_double(h[0]));
+    *dt = action_dt_from(c, a, as_double(h[ns0 + a]));
     return CMFP_OK;
 }
 
@@ -783,11 +805,15 @@ int cmfp_est_time_step(cmfp_context* c, double* out) {
     const int ns = (int)c->states.size(), na = (int)c->actions.size();
     std::vector<unsigned long long> h(ns + na, 0);
     for (int s = 0; s < ns; ++s)
-        if (c->states[s].sp.kind == CMFP_STATE_HYDRO)
+        if (c->states[s].sp.kind == CMFP_STATE_HYDRO && !c->red_valid[s]) {
             if ((r = launch_state_dt(c, s, s))) return r;
+            c->red_valid[s] = 1;
+        }
     for (int a = 0; a < na; ++a)
-        if (action_limits_dt(c->actions[a]))
+        if (action_limits_dt(c->actions[a]) && !c->red_valid[ns + a]) {
             if ((r = launch_action_dt(c, a, ns + a))) return r;
+            c->red_valid[ns + a] = 1;
+        }
     if ((r = reduce_words(c, h))) return r;
     double estdt = std::numeric_limits<double>::max();
     for (int s = 0; s < ns; ++s) estdt = std::min(estdt, state_dt_from(c, s, as_double(h[s])));
@@ -814,6 +840,7 @@ int cmfp_advance(cmfp_context* c, double, double dt) {
     int r;
     if ((r = check_ctx(c))) return r;
     c->last_fused = 0;
+    std::fill(c->red_valid.begin(), c->red_valid.end(), 0);
     if (c->fused) {
         r = advance_strang_fused(c, dt);
         if (r < 0) return r;

@@ -8,6 +8,7 @@
 // fully coalesced 8-byte lane accesses on every component plane.
 #include "mfp_device.h"
 
+#include <algorithm>
 #include <cfloat>
 
 namespace CMFP_NS {
@@ -427,29 +428,26 @@ CMFP_DEV void plasma5_implicit_cell(const SourceArgs& a, const SourceCoef& kf, d
 
 // staged form: dU += S(U) on the valid cells (Plasma5::calc_time_derivative
 // MFP_plasma5.cpp:73-85, Lorentz::calc_time_derivative MFP_lorentz.cpp:60-198)
+template <int NS, bool IMPL>
 __global__ void k_source(Geo g, IBox box, SourceArgs a, SourceCoef kf, double dt) {
     int i, j, k;
     if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
     const long c = g.at(i, j, k);
-    double fU[10], sU[4][5], sdU[4][4], fdU[5];
+    double fU[10], sU[NS][5], sdU[NS][4], fdU[5];
 #pragma unroll
     for (int n = 0; n < 10; ++n) fU[n] = a.f_U[c + n * g.sc];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (s < a.n_species) {
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int n = 0; n < 5; ++n) sU[s][n] = a.sp_U[s][c + n * g.sc];
-        }
-    if (a.implicit)
-        plasma5_implicit_cell<4>(a, kf, dt, fU, sU, sdU, fdU);
+        for (int n = 0; n < 5; ++n) sU[s][n] = a.sp_U[s][c + n * g.sc];
+    if (IMPL)
+        plasma5_implicit_cell<NS>(a, kf, dt, fU, sU, sdU, fdU);
     else
-        plasma5_explicit_cell<4>(a, kf, dt, fU, sU, sdU, fdU);
+        plasma5_explicit_cell<NS>(a, kf, dt, fU, sU, sdU, fdU);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (s < a.n_species) {
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) a.sp_dU[s][c + (n + 1) * g.sc] += sdU[s][n];
-        }
+        for (int n = 0; n < 4; ++n) a.sp_dU[s][c + (n + 1) * g.sc] += sdU[s][n];
     if (!a.lorentz_only) {
         a.f_dU[c + F_DX * g.sc] += fdU[0];
         a.f_dU[c + F_DY * g.sc] += fdU[1];
@@ -459,71 +457,11 @@ __global__ void k_source(Geo g, IBox box, SourceArgs a, SourceCoef kf, double dt
     }
 }
 
-// fused form of one Strang source stage with the RK2 inner integrator
-// (MFP_advance.cpp:146-197 / 235-281), in place on the new-time data:
-//   U1 = U0 + S(U0) ; U2 = U1 + S(U1) ; new = 0.5 U0 + 0.5 U2
-// Components no source touches are left as they are (the reference rewrites
-// them with 0.5 x + 0.5 (x + 0 + 0) = x).
-__global__ void k_source_rk2(Geo g, IBox box, SourceArgs a, SourceCoef kf, double dt) {
-    int i, j, k;
-    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
-    const long c = g.at(i, j, k);
-    double f0[10], s0[4][5], f1[10], s1[4][5], sdU[4][4], fdU[5];
-#pragma unroll
-    for (int n = 0; n < 10; ++n) f0[n] = a.f_U[c + n * g.sc];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (s < a.n_species) {
-#pragma unroll
-            for (int n = 0; n < 5; ++n) s0[s][n] = a.sp_U[s][c + n * g.sc];
-        }
-    // stage 1
-    if (a.implicit)
-        plasma5_implicit_cell<4>(a, kf, dt, f0, s0, sdU, fdU);
-    else
-        plasma5_explicit_cell<4>(a, kf, dt, f0, s0, sdU, fdU);
-#pragma unroll
-    for (int n = 0; n < 10; ++n) f1[n] = f0[n];
-    if (!a.lorentz_only) {
-        f1[F_DX] = f0[F_DX] + fdU[0];
-        f1[F_DY] = f0[F_DY] + fdU[1];
-        f1[F_DZ] = f0[F_DZ] + fdU[2];
-        f1[F_PHI] = f0[F_PHI] + fdU[3];
-        f1[F_PSI] = f0[F_PSI] + fdU[4];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (s < a.n_species) {
-            s1[s][0] = s0[s][0];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) s1[s][n + 1] = s0[s][n + 1] + sdU[s][n];
-        }
-    // stage 2
-    if (a.implicit)
-        plasma5_implicit_cell<4>(a, kf, dt, f1, s1, sdU, fdU);
-    else
-        plasma5_explicit_cell<4>(a, kf, dt, f1, s1, sdU, fdU);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (s < a.n_species) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const double U2 = s1[s][n + 1] + sdU[s][n];
-                a.sp_U[s][c + (n + 1) * g.sc] = 0.5 * s0[s][n + 1] + 0.5 * U2;
-            }
-        }
-    if (!a.lorentz_only) {
-        a.f_U[c + F_DX * g.sc] = 0.5 * f0[F_DX] + 0.5 * (f1[F_DX] + fdU[0]);
-        a.f_U[c + F_DY * g.sc] = 0.5 * f0[F_DY] + 0.5 * (f1[F_DY] + fdU[1]);
-        a.f_U[c + F_DZ * g.sc] = 0.5 * f0[F_DZ] + 0.5 * (f1[F_DZ] + fdU[2]);
-        a.f_U[c + F_PHI * g.sc] = 0.5 * f0[F_PHI] + 0.5 * (f1[F_PHI] + fdU[3]);
-        a.f_U[c + F_PSI * g.sc] = 0.5 * f0[F_PSI] + 0.5 * (f1[F_PSI] + fdU[4]);
-    }
-}
-
 // ------------------------------------------------------------- dt reductions
-// Positive doubles order like their bit patterns, so the chip-wide max / min
-// is one 64-bit integer atomic per block after a wave64 shuffle reduction.
+// Block partials are written with plain stores (no contended atomics: 64 Ki
+// single-address atomics cost ~0.75 ms on MI355X); a one-block kernel folds them.
+static constexpr int RED_BLOCKS = 2048;
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -534,57 +472,162 @@ __device__ __forceinline__ double wave_min(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
     return v;
 }
-
-// EulerianState::get_allowed_time_step MFP_eulerian.cpp:255-300: max over valid
-// cells and over d < DIM of get_speed_from_cons.
-__global__ void k_max_speed(Geo g, IBox box, HydroParams hp, const double* __restrict__ U, unsigned long long* out) {
-    __shared__ double part[TPB / 64];
-    int i, j, k;
-    double m = DBL_MIN;  // std::numeric_limits<Real>::min()  (:265)
-    if (decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) {
-        const long c = g.at(i, j, k);
-        double u[5], s[3];
-#pragma unroll
-        for (int n = 0; n < 5; ++n) u[n] = U[c + n * g.sc];
-        hydro_speed_from_cons(hp.gas, u, s);
-        for (int d = 0; d < g.dim; ++d) m = std_max(m, s[d]);
-    }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+template <bool IS_MAX> __device__ __forceinline__ void block_reduce_store(double v, double* part) {
+    __shared__ double sh[TPB / 64];
+    v = IS_MAX ? wave_max(v) : wave_min(v);
+    __syncthreads();  // sh may be reused by a previous call
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < TPB / 64; ++w) m = fmax(m, part[w]);
-        atomicMax(out, (unsigned long long)__double_as_longlong(m));
+        for (int w = 1; w < TPB / 64; ++w) v = IS_MAX ? fmax(v, sh[w]) : fmin(v, sh[w]);
+        part[blockIdx.x] = v;
+    }
+}
+// folds nb block partials into *out (the bit pattern of the double)
+__global__ void k_reduce_final(const double* __restrict__ part, int nb, int is_max, unsigned long long* out) {
+    double v = is_max ? DBL_MIN : DBL_MAX;
+    for (int t = threadIdx.x; t < nb; t += TPB) v = is_max ? fmax(v, part[t]) : fmin(v, part[t]);
+    __shared__ double sh[TPB / 64];
+    v = is_max ? wave_max(v) : wave_min(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; ++w) v = is_max ? fmax(v, sh[w]) : fmin(v, sh[w]);
+        *out = (unsigned long long)__double_as_longlong(v);
     }
 }
 
-// Plasma5::get_allowed_time_step MFP_plasma5.cpp:522-557 (cell loop part)
-__global__ void k_plasma_dt(Geo g, IBox box, SourceArgs a, unsigned long long* out) {
-    __shared__ double part[TPB / 64];
-    int i, j, k;
-    double dt = DBL_MAX;
-    if (decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) {
+// per-cell contributions
+// EulerianState::get_allowed_time_step MFP_eulerian.cpp:290-296
+CMFP_DEV double cell_max_speed(const GasP& G, const double* U, int dim, double m) {
+    double s[3];
+    hydro_speed_from_cons(G, U, s);
+    for (int d = 0; d < dim; ++d) m = std_max(m, s[d]);
+    return m;
+}
+// Plasma5::get_allowed_time_step MFP_plasma5.cpp:535-555
+CMFP_DEV double cell_plasma_dt(double Larmor, double Debye, double Bx, double By, double Bz, double rho, double r, double dt) {
+    const double PI = 3.141592653589793;  // acos(-1)
+    const double D2 = Debye * Debye;
+    const double B = sqrt(Bx * Bx + By * By + Bz * Bz);
+    const double omega_p = 10 * sqrt(rho * r * r / D2) / (2 * PI);
+    if (omega_p > 0) dt = std_min(dt, 1 / omega_p);
+    const double omega_c = 10 * (fabs(r) * B) / (Larmor * 2 * PI);
+    if (omega_c > 0) dt = std_min(dt, 1 / omega_c);
+    return dt;
+}
+
+// fused form of one Strang source stage with the RK2 inner integrator
+// (MFP_advance.cpp:146-197 / 235-281), in place on the new-time data:
+//   U1 = U0 + S(U0) ; U2 = U1 + S(U1) ; new = 0.5 U0 + 0.5 U2
+// Components no source touches are left as they are (the reference rewrites
+// them with 0.5 x + 0.5 (x + 0 + 0) = x).  With REDUCE the kernel also leaves
+// the block partials of the CFL quantities of the values it just wrote
+// (max a+|u_d| per species, min plasma/cyclotron dt), so the dt estimate of the
+// next step costs no extra pass over the state.
+template <int NS, bool IMPL, bool REDUCE>
+__global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs a, SourceCoef kf, double dt) {
+    const long npts = box.npts();
+    double red_speed[NS];
+    double red_dt = DBL_MAX;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) red_speed[s] = DBL_MIN;
+    for (long t = (long)blockIdx.x * TPB + threadIdx.x; t < npts; t += (long)gridDim.x * TPB) {
+        int i, j, k;
+        decode(box, t, i, j, k);
         const long c = g.at(i, j, k);
-        const double PI = 3.141592653589793;  // acos(-1)
-        const double D2 = a.Debye * a.Debye;
-        const double Bx = a.f_U[c + F_BX * g.sc], By = a.f_U[c + F_BY * g.sc], Bz = a.f_U[c + F_BZ * g.sc];
-        const double B = sqrt(Bx * Bx + By * By + Bz * Bz);
-        for (int n = 0; n < a.n_species; ++n) {
-            const double rho = a.sp_U[n][c];
-            const double r = a.r[n];
-            const double omega_p = 10 * sqrt(rho * r * r / D2) / (2 * PI);
-            if (omega_p > 0) dt = std_min(dt, 1 / omega_p);
-            const double omega_c = 10 * (fabs(r) * B) / (a.Larmor * 2 * PI);
-            if (omega_c > 0) dt = std_min(dt, 1 / omega_c);
+        double f0[10], s0[NS][5], f1[10], s1[NS][5], sdU[NS][4], fdU[5];
+#pragma unroll
+        for (int n = 0; n < 10; ++n) f0[n] = a.f_U[c + n * g.sc];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int n = 0; n < 5; ++n) s0[s][n] = a.sp_U[s][c + n * g.sc];
+        // stage 1
+        if (IMPL)
+            plasma5_implicit_cell<NS>(a, kf, dt, f0, s0, sdU, fdU);
+        else
+            plasma5_explicit_cell<NS>(a, kf, dt, f0, s0, sdU, fdU);
+#pragma unroll
+        for (int n = 0; n < 10; ++n) f1[n] = f0[n];
+        if (!a.lorentz_only) {
+            f1[F_DX] = f0[F_DX] + fdU[0];
+            f1[F_DY] = f0[F_DY] + fdU[1];
+            f1[F_DZ] = f0[F_DZ] + fdU[2];
+            f1[F_PHI] = f0[F_PHI] + fdU[3];
+            f1[F_PSI] = f0[F_PSI] + fdU[4];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            s1[s][0] = s0[s][0];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) s1[s][n + 1] = s0[s][n + 1] + sdU[s][n];
+        }
+        // stage 2
+        if (IMPL)
+            plasma5_implicit_cell<NS>(a, kf, dt, f1, s1, sdU, fdU);
+        else
+            plasma5_explicit_cell<NS>(a, kf, dt, f1, s1, sdU, fdU);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            double Un[5];
+            Un[0] = s0[s][0];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const double U2 = s1[s][n + 1] + sdU[s][n];
+                Un[n + 1] = 0.5 * s0[s][n + 1] + 0.5 * U2;
+                a.sp_U[s][c + (n + 1) * g.sc] = Un[n + 1];
+            }
+            if (REDUCE) {
+                GasP G{1.0, 0.0, a.gamma[s]};
+                red_speed[s] = cell_max_speed(G, Un, g.dim, red_speed[s]);
+                if (a.limits_dt) red_dt = cell_plasma_dt(a.Larmor, a.Debye, f0[F_BX], f0[F_BY], f0[F_BZ], Un[0], a.r[s], red_dt);
+            }
+        }
+        if (!a.lorentz_only) {
+            a.f_U[c + F_DX * g.sc] = 0.5 * f0[F_DX] + 0.5 * (f1[F_DX] + fdU[0]);
+            a.f_U[c + F_DY * g.sc] = 0.5 * f0[F_DY] + 0.5 * (f1[F_DY] + fdU[1]);
+            a.f_U[c + F_DZ * g.sc] = 0.5 * f0[F_DZ] + 0.5 * (f1[F_DZ] + fdU[2]);
+            a.f_U[c + F_PHI * g.sc] = 0.5 * f0[F_PHI] + 0.5 * (f1[F_PHI] + fdU[3]);
+            a.f_U[c + F_PSI * g.sc] = 0.5 * f0[F_PSI] + 0.5 * (f1[F_PSI] + fdU[4]);
         }
     }
-    dt = wave_min(dt);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = dt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < TPB / 64; ++w) dt = fmin(dt, part[w]);
-        atomicMin(out, (unsigned long long)__double_as_longlong(dt));
+    if (REDUCE) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) block_reduce_store<true>(red_speed[s], a.part_speed[s]);
+        if (a.limits_dt) block_reduce_store<false>(red_dt, a.part_dt);
     }
+}
+
+// EulerianState::get_allowed_time_step MFP_eulerian.cpp:255-300: max over valid
+// cells and over d < DIM of get_speed_from_cons.
+__global__ void k_max_speed(Geo g, IBox box, HydroParams hp, const double* __restrict__ U, double* part) {
+    const long npts = box.npts();
+    double m = DBL_MIN;  // std::numeric_limits<Real>::min()  (:265)
+    for (long t = (long)blockIdx.x * TPB + threadIdx.x; t < npts; t += (long)gridDim.x * TPB) {
+        int i, j, k;
+        decode(box, t, i, j, k);
+        const long c = g.at(i, j, k);
+        double u[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) u[n] = U[c + n * g.sc];
+        m = cell_max_speed(hp.gas, u, g.dim, m);
+    }
+    block_reduce_store<true>(m, part);
+}
+
+// Plasma5::get_allowed_time_step MFP_plasma5.cpp:522-557 (cell loop part)
+__global__ void k_plasma_dt(Geo g, IBox box, SourceArgs a, double* part) {
+    const long npts = box.npts();
+    double dt = DBL_MAX;
+    for (long t = (long)blockIdx.x * TPB + threadIdx.x; t < npts; t += (long)gridDim.x * TPB) {
+        int i, j, k;
+        decode(box, t, i, j, k);
+        const long c = g.at(i, j, k);
+        const double Bx = a.f_U[c + F_BX * g.sc], By = a.f_U[c + F_BY * g.sc], Bz = a.f_U[c + F_BZ * g.sc];
+        for (int n = 0; n < a.n_species; ++n) dt = cell_plasma_dt(a.Larmor, a.Debye, Bx, By, Bz, a.sp_U[n][c], a.r[n], dt);
+    }
+    block_reduce_store<false>(dt, part);
 }
 
 // ------------------------------------------------------------------ ghosts
@@ -813,23 +856,63 @@ static void l_lincomb(const Geo& g, int nc, double* dst, double a, const double*
     LAUNCH(k_lincomb, b.npts(), st, g, b, nc, dst, a, x, bb, y);
 }
 
-static void l_source(const Geo& g, const SourceArgs& a, double dt, hipStream_t st) {
+template <int NS> static void l_source_n(const Geo& g, const SourceArgs& a, double dt, hipStream_t st) {
     IBox b = valid_box(g);
-    LAUNCH(k_source, b.npts(), st, g, b, a, source_coef(a, dt), dt);
+    if (a.implicit)
+        LAUNCH((k_source<NS, true>), b.npts(), st, g, b, a, source_coef(a, dt), dt);
+    else
+        LAUNCH((k_source<NS, false>), b.npts(), st, g, b, a, source_coef(a, dt), dt);
 }
-static int l_source_fused(const Geo& g, const SourceArgs& a, double dt, hipStream_t st) {
+static void l_source(const Geo& g, const SourceArgs& a, double dt, hipStream_t st) {
+    switch (a.n_species) {
+    case 1: l_source_n<1>(g, a, dt, st); break;
+    case 2: l_source_n<2>(g, a, dt, st); break;
+    case 3: l_source_n<3>(g, a, dt, st); break;
+    case 4: l_source_n<4>(g, a, dt, st); break;
+    }
+}
+static unsigned red_blocks(long npts) { return (unsigned)std::min<long>(nblocks(npts), RED_BLOCKS); }
+
+template <int NS> static void l_source_rk2_n(const Geo& g, const SourceArgs& a, double dt, int reduce, hipStream_t st) {
     IBox b = valid_box(g);
-    LAUNCH(k_source_rk2, b.npts(), st, g, b, a, source_coef(a, dt), dt);
+    const unsigned nb = red_blocks(b.npts());
+    const SourceCoef kf = source_coef(a, dt);
+#define RK2(I, R) hipLaunchKernelGGL((k_source_rk2<NS, I, R>), dim3(nb), dim3(TPB), 0, st, g, b, a, kf, dt)
+    if (a.implicit) {
+        if (reduce) RK2(true, true); else RK2(true, false);
+    } else {
+        if (reduce) RK2(false, true); else RK2(false, false);
+    }
+#undef RK2
+    if (reduce) {
+        for (int s = 0; s < NS; ++s)
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, a.part_speed[s], (int)nb, 1, a.out_speed[s]);
+        if (a.limits_dt) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, a.part_dt, (int)nb, 0, a.out_dt);
+    }
+}
+static int l_source_fused(const Geo& g, const SourceArgs& a, double dt, int reduce, hipStream_t st) {
+    switch (a.n_species) {
+    case 1: l_source_rk2_n<1>(g, a, dt, reduce, st); break;
+    case 2: l_source_rk2_n<2>(g, a, dt, reduce, st); break;
+    case 3: l_source_rk2_n<3>(g, a, dt, reduce, st); break;
+    case 4: l_source_rk2_n<4>(g, a, dt, reduce, st); break;
+    default: return 0;
+    }
     return 1;
 }
 
-static void l_max_speed(const Geo& g, const StatePhys& sp, const double* U, unsigned long long* out, hipStream_t st) {
+static void l_max_speed(const Geo& g, const StatePhys& sp, const double* U, double* part, unsigned long long* out,
+                        hipStream_t st) {
     IBox b = valid_box(g);
-    LAUNCH(k_max_speed, b.npts(), st, g, b, sp.hp, U, out);
+    const unsigned nb = red_blocks(b.npts());
+    hipLaunchKernelGGL(k_max_speed, dim3(nb), dim3(TPB), 0, st, g, b, sp.hp, U, part);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, part, (int)nb, 1, out);
 }
-static void l_plasma_dt(const Geo& g, const SourceArgs& a, unsigned long long* out, hipStream_t st) {
+static void l_plasma_dt(const Geo& g, const SourceArgs& a, double* part, unsigned long long* out, hipStream_t st) {
     IBox b = valid_box(g);
-    LAUNCH(k_plasma_dt, b.npts(), st, g, b, a, out);
+    const unsigned nb = red_blocks(b.npts());
+    hipLaunchKernelGGL(k_plasma_dt, dim3(nb), dim3(TPB), 0, st, g, b, a, part);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, part, (int)nb, 0, out);
 }
 
 static IBox ghost_slab(const Geo& g, int d, int ngs, int lo_other_full) {

@@ -52,6 +52,8 @@ struct StatePhys {
     int bc[10][3][2];
 };
 
+constexpr int CMFP_RED_BLOCKS = 2048;  // block partials per reduction word
+
 struct Ptr3 {
     double* p[3];
 };
@@ -70,6 +72,13 @@ struct SourceArgs {
     double c_h, div_damp;
     int lorentz_only;
     int implicit;
+    // fused CFL reduction (k_source_rk2<..., REDUCE>)
+    double gamma[4];                  // species gamma
+    int limits_dt;                    // plasma5 explicit: plasma / cyclotron dt limit (MFP_plasma5.cpp:461)
+    double* part_speed[4];            // block partials (RED_BLOCKS doubles each)
+    double* part_dt;
+    unsigned long long* out_speed[4];  // final words
+    unsigned long long* out_dt;
 };
 
 // ghost fill rule per component for one (dim, side)
@@ -99,15 +108,15 @@ struct Launchers {
     // sources (staged: accumulate into dU)
     void (*source)(const Geo&, const SourceArgs&, double dt, hipStream_t);
     // dt limits: result combined into *out (bits of a positive double) with atomics
-    void (*max_speed)(const Geo&, const StatePhys&, const double* U, unsigned long long* out, hipStream_t);
-    void (*plasma_dt)(const Geo&, const SourceArgs&, unsigned long long* out, hipStream_t);
+    void (*max_speed)(const Geo&, const StatePhys&, const double* U, double* part, unsigned long long* out, hipStream_t);
+    void (*plasma_dt)(const Geo&, const SourceArgs&, double* part, unsigned long long* out, hipStream_t);
     // ghosts
     void (*fill_dim)(const Geo&, int nc, int ngs, double* A, int d, int side, FillRules, hipStream_t);
     void (*pack)(const Geo&, int nc, int ngs, double* A, int d, int side, double* buf, int unpack, hipStream_t);
     // fused paths (return 0 when the option set is not covered)
     int (*ctu_fused)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
                      const int touches[3][2], int* err, hipStream_t);
-    int (*source_fused)(const Geo&, const SourceArgs&, double dt, hipStream_t);
+    int (*source_fused)(const Geo&, const SourceArgs&, double dt, int reduce, hipStream_t);
     // batched leaves
     int (*leaf_reconstruct)(int recon, long n, const double* st, double* slope, double* lo, double* hi, hipStream_t);
     int (*leaf_riemann)(int flux, long n, const double* L, const double* R, double* F, double c0, double ch,
