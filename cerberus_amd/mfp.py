@@ -203,43 +203,77 @@ class MFP:
             c[d] %= self.grid[d]
         return coords_rank(c, self.grid)
 
+    # The three hooks below are all the exchange needs from the device side;
+    # tests/test_exchange_gloo.py overrides them with a host emulation to run
+    # the protocol on CPU ranks.
+    def _halo_count(self, s, d):
+        return int(self.L.cmfp_halo_count(self.h, s, d))
+
+    def _halo_pack(self, s, d, side, buf):
+        self._chk(self.L.cmfp_halo_pack(self.h, s, d, side, C.c_void_p(buf.data_ptr())))
+
+    def _halo_unpack(self, s, d, side, buf):
+        self._chk(self.L.cmfp_halo_unpack(self.h, s, d, side, C.c_void_p(buf.data_ptr())))
+
+    def _buffers(self, s, d):
+        import torch
+        key = (s, d)
+        if key not in self._bufs:
+            n = self._halo_count(s, d)
+            dev = self._pack_device()
+            dbuf = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(4)]
+            if self._exchange_device is not None and torch.device(self._exchange_device) != dev:
+                # host-staged transport (gloo): pinned mirrors of the four device buffers
+                hbuf = [torch.empty(n, dtype=torch.float64, device=self._exchange_device) for _ in range(4)]
+            else:
+                hbuf = dbuf
+            self._bufs[key] = (dbuf, hbuf)
+        return self._bufs[key]
+
+    def _pack_device(self):
+        import torch
+        return torch.device("cuda", torch.cuda.current_device())
+
     def _exchange(self, user, ctx, s, d):
-        """cmfp_exchange_fn: pack both faces, swap with the neighbours, unpack."""
+        """cmfp_exchange_fn: pack both faces, swap with the neighbours, unpack.
+        Buffers 0/1 = send lo/hi, 2/3 = recv lo/hi."""
         try:
-            import torch
             import torch.distributed as dist
-            n = int(self.L.cmfp_halo_count(self.h, s, d))
-            key = (s, d)
-            if key not in self._bufs:
-                dev = torch.device("cuda", torch.cuda.current_device())
-                self._bufs[key] = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(4)]
-            send_lo, send_hi, recv_lo, recv_hi = self._bufs[key]
+            dbuf, xbuf = self._buffers(s, d)
+            staged = xbuf is not dbuf
             nb_lo, nb_hi = self.neighbour(d, 0), self.neighbour(d, 1)
+            if nb_lo is not None:
+                self._halo_pack(s, d, 0, dbuf[0])
+            if nb_hi is not None:
+                self._halo_pack(s, d, 1, dbuf[1])
+            if staged:
+                for k in (0, 1):
+                    xbuf[k].copy_(dbuf[k])
             ops = []
-            if nb_lo is not None:
-                self._chk(self.L.cmfp_halo_pack(self.h, s, d, 0, C.c_void_p(send_lo.data_ptr())))
-            if nb_hi is not None:
-                self._chk(self.L.cmfp_halo_pack(self.h, s, d, 1, C.c_void_p(send_hi.data_ptr())))
-            if nb_lo is not None:
-                ops.append(dist.P2POp(dist.isend, send_lo, nb_lo, group=self.pg))
-                ops.append(dist.P2POp(dist.irecv, recv_lo, nb_lo, group=self.pg))
-            if nb_hi is not None:
-                ops.append(dist.P2POp(dist.isend, send_hi, nb_hi, group=self.pg))
-                ops.append(dist.P2POp(dist.irecv, recv_hi, nb_hi, group=self.pg))
+            if nb_lo is not None and nb_lo == nb_hi:
+                # two ranks along a periodic dimension: both messages go to the same peer and are
+                # matched in order; the peer's low face (its first send) is my high ghost
+                ops = [dist.P2POp(dist.isend, xbuf[0], nb_lo, group=self.pg),
+                       dist.P2POp(dist.isend, xbuf[1], nb_hi, group=self.pg),
+                       dist.P2POp(dist.irecv, xbuf[3], nb_hi, group=self.pg),
+                       dist.P2POp(dist.irecv, xbuf[2], nb_lo, group=self.pg)]
+            else:
+                if nb_lo is not None:
+                    ops.append(dist.P2POp(dist.isend, xbuf[0], nb_lo, group=self.pg))
+                    ops.append(dist.P2POp(dist.irecv, xbuf[2], nb_lo, group=self.pg))
+                if nb_hi is not None:
+                    ops.append(dist.P2POp(dist.isend, xbuf[1], nb_hi, group=self.pg))
+                    ops.append(dist.P2POp(dist.irecv, xbuf[3], nb_hi, group=self.pg))
             if ops:
-                if nb_lo == nb_hi and nb_lo is not None:
-                    # two ranks along a periodic dimension: both messages go to the same
-                    # peer; order the recvs to match the peer's sends (its hi face is my lo ghost)
-                    ops = [dist.P2POp(dist.isend, send_lo, nb_lo, group=self.pg),
-                           dist.P2POp(dist.isend, send_hi, nb_hi, group=self.pg),
-                           dist.P2POp(dist.irecv, recv_hi, nb_hi, group=self.pg),
-                           dist.P2POp(dist.irecv, recv_lo, nb_lo, group=self.pg)]
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
+            if staged:
+                for k in (2, 3):
+                    dbuf[k].copy_(xbuf[k])
             if nb_lo is not None:
-                self._chk(self.L.cmfp_halo_unpack(self.h, s, d, 0, C.c_void_p(recv_lo.data_ptr())))
+                self._halo_unpack(s, d, 0, dbuf[2])
             if nb_hi is not None:
-                self._chk(self.L.cmfp_halo_unpack(self.h, s, d, 1, C.c_void_p(recv_hi.data_ptr())))
+                self._halo_unpack(s, d, 1, dbuf[3])
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             import traceback

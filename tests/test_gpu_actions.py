@@ -1,0 +1,213 @@
+"""Action-API level parity (one call per virtual of class Action), ghost fill,
+dt limits, option coverage and error behaviour on the GPU against the oracle."""
+import numpy as np
+import pytest
+
+from cerberus_amd import abi, config, lib, problems
+from helpers import rel_linf, small_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(P, **kw):
+    from cerberus_amd.mfp import MFP
+    m = MFP(P, **kw)
+    m.init_data()
+    return m
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_action_dU_and_dt_limits(oracle, case):
+    """get_data + calc_time_derivative + calc_spatial_derivative of every action,
+    get_allowed_time_step of every state and action: bit-exact in STRICT mode."""
+    name, cfg, _ = small_cases()[case]
+    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    ref = oracle.OracleSim(P)
+    m = _gpu(P)
+    dt = ref.est_time_step()
+    v = m.est_time_step()
+    assert v == dt
+    for s in range(m.n_states):
+        assert m.state_allowed_dt(s) == ref.state_allowed_dt(s)
+    for a in range(m.n_actions):
+        assert m.action_allowed_dt(a) == ref.action_allowed_dt(a)
+        m.update_begin()
+        m.action_get_data(a)
+        m.action_calc_time_derivative(a, 0.5 * dt)
+        m.action_calc_spatial_derivative(a, dt)
+        ad = P.action_descs()[a]
+        for i in range(ad.n_states):
+            s = ad.states[i]
+            if ad.kind == abi.ACTION["CTU"]:
+                exp = ref.action_dU(a, dt, s)
+            else:
+                exp = ref.action_dU(a, 0.5 * dt, s)
+            got = m.update_download(s, 1)
+            assert np.array_equal(got, exp), (name, P.action_names[a], P.state_names[s], rel_linf(got, exp))
+    m.close()
+
+
+@pytest.mark.parametrize("case", [3, 4, 0])
+def test_fill_patch_matches_oracle(oracle, case):
+    import ctypes as C
+    import torch
+    name, cfg, _ = small_cases()[case]
+    P = config.Problem(cfg)
+    ref = oracle.OracleSim(P)
+    m = _gpu(P)
+    for s in range(m.n_states):
+        m.fill_patch(s)
+        ptr, ng, ext, nc = m.device_view(s)
+        n = nc * ext[0] * ext[1] * ext[2]
+        host = np.empty(n)
+        torch.cuda.synchronize()
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(8 * n), 2) == 0
+        A = host.reshape(nc, ext[2], ext[1], ext[0])
+        G = ref.fill_patch(s)                       # domain grown by the state's own num_grow
+        gs = m.L.cmfp_state_ngrow(m.h, s)
+        off = ng - gs
+        sl = tuple(slice(off, e - off) if d < P.dim else slice(None) for d, e in zip((2, 1, 0), (ext[2], ext[1], ext[0])))
+        assert np.array_equal(A[(slice(None),) + sl], G), (name, P.state_names[s])
+    m.close()
+
+
+OPTION_CASES = [
+    ("implicit", lambda: problems.orszag_tang_two_fluid_2d(32, solver="implicit"), 1e-12, 1e-12),
+    ("lorentz", lambda: problems.orszag_tang_two_fluid_2d(32, source="Lorentz"), 0.0, 1e-12),
+]
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("idx", range(len(OPTION_CASES)))
+def test_source_variants(oracle, idx, fused):
+    name, mk, tol_strict, tol_fast = OPTION_CASES[idx]
+    for mode, tol in ((abi.FP_STRICT, tol_strict), (abi.FP_FAST, tol_fast)):
+        P = config.Problem(mk(), fp_mode=mode)
+        ref = oracle.OracleSim(P)
+        ref.run(6)
+        m = _gpu(P, fused=fused)
+        m.run(6)
+        assert m.last_advance_fused() == fused
+        for s in range(m.n_states):
+            assert rel_linf(m.download(s), ref.get_state(s)) <= tol, (name, mode, P.state_names[s])
+        m.close()
+
+
+def _kh(recon, flux, scheme="strang", ctu=True, thr=None, n=32):
+    cfg = problems.kelvin_helmholtz_2d(n, flux=flux, recon=recon)
+    cfg["time_integration_scheme"] = scheme
+    cfg["actions"]["fluxes"]["corner_transport"] = ctu
+    if thr:
+        cfg["states"]["fluid"]["shock_detector"] = {"name": "pressure_jump_detector", "threshold": thr}
+    return cfg
+
+
+@pytest.mark.parametrize("recon", ["constant", "minmod", "vanLeer", "MC", "centre", "O6", "WENO"])
+@pytest.mark.parametrize("flux", ["HLLC", "HLLE"])
+def test_hydro_option_matrix(oracle, recon, flux):
+    P = config.Problem(_kh(recon, flux), fp_mode=abi.FP_STRICT)
+    ref = oracle.OracleSim(P)
+    ref.run(5)
+    for fused in (False, True):
+        m = _gpu(P, fused=fused)
+        m.run(5)
+        assert np.array_equal(m.download(0), ref.get_state(0)), (recon, flux, fused)
+        m.close()
+
+
+@pytest.mark.parametrize("scheme,ctu,thr", [("euler", True, None), ("RK2", True, None), ("strang", False, None),
+                                            ("strang", True, 0.3), ("RK2", False, 0.3)])
+def test_integrators_and_hybrid_flux(oracle, scheme, ctu, thr):
+    flux = "HLLE/HLLC" if thr else "HLLC"
+    P = config.Problem(_kh("minmod", flux, scheme, ctu, thr), fp_mode=abi.FP_STRICT)
+    ref = oracle.OracleSim(P)
+    ref.run(5)
+    m = _gpu(P)
+    m.run(5)
+    assert np.array_equal(m.download(0), ref.get_state(0))
+    m.close()
+
+
+def test_field_reconstruction_options(oracle):
+    for recon in ("minmod", "vanLeer", "O6", "WENO", "MC"):
+        cfg = problems.orszag_tang_two_fluid_2d(24)
+        cfg["states"]["field"]["reconstruction"] = recon
+        P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+        ref = oracle.OracleSim(P)
+        ref.run(4)
+        m = _gpu(P)
+        m.run(4)
+        for s in range(3):
+            assert np.array_equal(m.download(s), ref.get_state(s)), (recon, s)
+        m.close()
+
+
+def test_fused_path_is_taken_for_2d_strang():
+    for case in (1, 2, 3):
+        name, cfg, _ = small_cases()[case]
+        m = _gpu(config.Problem(cfg))
+        m.run(1)
+        assert m.last_advance_fused(), name
+        m.close()
+    name, cfg, _ = small_cases()[0]
+    m = _gpu(config.Problem(cfg))
+    m.run(1)
+    assert not m.last_advance_fused()      # 1-D takes the staged kernels
+    m.close()
+
+
+def test_unphysical_state_is_reported_not_aborted():
+    """rho, p, T <= 0: the reference aborts (MFP_hydro_gas.cpp:152-164); the ABI returns CMFP_ERR_PHYSICS."""
+    P = config.Problem(problems.kelvin_helmholtz_2d(32))
+    m = _gpu(P)
+    U = P.initial_data(0)
+    U[4, 0, 10, 10] = -1.0      # negative total energy -> negative pressure
+    m.upload(0, U)
+    m.advance(1e-4)
+    with pytest.raises(lib.CmfpError) as e:
+        m.download(0)
+    assert e.value.code == abi.ERR_PHYSICS
+    m.close()
+
+
+def test_ragged_sizes(oracle):
+    """block sizes that are not multiples of the fused tile (14 x 14 cells)"""
+    for n in ([17, 31], [45, 16]):
+        cfg = problems.orszag_tang_two_fluid_2d(16)
+        cfg["n_cell"] = n
+        P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+        ref = oracle.OracleSim(P)
+        ref.run(3)
+        m = _gpu(P)
+        m.run(3)
+        assert m.last_advance_fused()
+        for s in range(3):
+            assert np.array_equal(m.download(s), ref.get_state(s)), (n, s)
+        m.close()
+
+
+def test_full_size_properties():
+    """At BASELINE size (2048^2 KH) the oracle is too slow; check what the scheme
+    guarantees: exact periodic conservation to rounding, fused == staged kernels
+    bit for bit (STRICT mode; FMA contraction differs between the two in FAST
+    mode, checked to 1e-12 below), positivity."""
+    P = config.Problem(problems.kelvin_helmholtz_2d(2048), fp_mode=abi.FP_STRICT)
+    a, b = _gpu(P, fused=True), _gpu(P, fused=False)
+    U0 = P.initial_data(0)
+    a.run(3)
+    b.run(3)
+    A, B = a.download(0), b.download(0)
+    assert np.array_equal(A, B)
+    for c in range(5):
+        tot0, tot1 = U0[c].sum(dtype=np.longdouble), A[c].sum(dtype=np.longdouble)
+        assert abs(tot1 - tot0) <= 1e-11 * np.abs(U0[c]).sum(dtype=np.longdouble)
+    assert A[0].min() > 0
+    a.close()
+    b.close()
+    Pf = config.Problem(problems.kelvin_helmholtz_2d(2048), fp_mode=abi.FP_FAST)
+    f = _gpu(Pf, fused=True)
+    f.run(3)
+    assert rel_linf(f.download(0), A) <= 1e-12
+    f.close()

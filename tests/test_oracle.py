@@ -1,0 +1,199 @@
+"""The CPU oracle against (a) the known-answer vectors the survey recorded from
+the reference's own leaf sources (tests/golden/survey_kat.json),
+(b) analytic solutions in the style of the reference's Exec/testing/*/check.py,
+(c) structural properties the reference has by construction (independence of the
+box decomposition, conservation, periodic symmetry)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from cerberus_amd import abi, config, problems
+from helpers import rel_linf, small_cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "survey_kat.json")))
+col = lambda v: np.array(v, dtype=float)[:, None]
+
+
+# ---- (a) known-answer vectors: bit-exact -----------------------------------
+def test_kat_hllc_hlle(oracle):
+    assert np.array_equal(oracle.riemann(0, col(KAT["hydro_L"]), col(KAT["hydro_R"]))[:, 0], KAT["HLLC_F"])
+    assert np.array_equal(oracle.riemann(1, col(KAT["hydro_L"]), col(KAT["hydro_R"]))[:, 0], KAT["HLLE_F"])
+
+
+@pytest.mark.parametrize("name,r,key", [("minmod", 1, "stencil3"), ("vanLeer", 2, "stencil3"), ("MC", 3, "stencil3"),
+                                         ("O6", 5, "stencil7"), ("WENO", 6, "stencil7")])
+def test_kat_reconstruction(oracle, name, r, key):
+    s, lo, hi = oracle.reconstruct(r, col(KAT[key]))
+    assert [lo[0], hi[0]] == KAT[name]
+
+
+def test_kat_field_rh(oracle):
+    F = oracle.riemann(10, col(KAT["field_L"]), col(KAT["field_R"]), c0=KAT["field_c0"], ch=KAT["field_ch"])[:, 0]
+    assert np.array_equal(F, KAT["field_F"])
+
+
+def test_kat_gas(oracle):
+    g = KAT["gas"]
+    Q, s = oracle.cons2prim(g["mass"], g["gamma"], col(KAT["gas_U"]))
+    assert np.array_equal(Q[:, 0], KAT["gas_Q"])
+    assert list(s[:2, 0]) == KAT["gas_speeds_xy"]
+    U = oracle.prim2cons(g["mass"], g["gamma"], Q)
+    np.testing.assert_allclose(U[:, 0], KAT["gas_U"], rtol=2e-16)
+
+
+def implicit_matrix(im):
+    Ns, N = im["Ns"], 3 * (im["Ns"] + 1)
+    dt, L, D, c, B = im["dt"], im["Larmor"], im["Debye"], im["c"], im["B"]
+    A, b = np.eye(N), np.zeros(N)
+    for n, (r, rho, m) in enumerate(zip(im["r"], im["rho"], [im["m_ion"], im["m_ele"]])):
+        tB, tC, mc = -dt * r * rho * c / L, dt * r * L / (c * D * D), dt * r / L   # MFP_plasma5.cpp:373-375
+        A[3 * n + 0, 3 * n + 1], A[3 * n + 0, 3 * n + 2] = -B[2] * mc, B[1] * mc
+        A[3 * n + 1, 3 * n + 0], A[3 * n + 1, 3 * n + 2] = B[2] * mc, -B[0] * mc
+        A[3 * n + 2, 3 * n + 0], A[3 * n + 2, 3 * n + 1] = -B[1] * mc, B[0] * mc
+        for i in range(3):
+            A[3 * n + i, 3 * Ns + i], A[3 * Ns + i, 3 * n + i] = tB, tC
+        b[3 * n:3 * n + 3] = m
+    b[3 * Ns:] = im["E"]
+    return A, b
+
+
+def test_kat_implicit_system(oracle):
+    A, b = implicit_matrix(KAT["implicit"])
+    x = oracle.colpiv_solve(A, b)
+    sol = np.array(KAT["implicit"]["solution"])
+    assert np.abs(x - sol).max() / np.abs(sol).max() < 1e-13
+
+
+# ---- (b) analytic: Sod shock tube (exact Riemann solution, Toro ch. 4) -------
+def sod_exact(x, t, gam=1.4, left=(1.0, 0.0, 1.0), right=(0.125, 0.0, 0.1)):
+    rl, ul, pl = left
+    rr, ur, pr = right
+    al, ar = math.sqrt(gam * pl / rl), math.sqrt(gam * pr / rr)
+
+    def f(p, r, pk, a):
+        if p > pk:
+            A, B = 2 / ((gam + 1) * r), (gam - 1) / (gam + 1) * pk
+            return (p - pk) * math.sqrt(A / (p + B))
+        return 2 * a / (gam - 1) * ((p / pk) ** ((gam - 1) / (2 * gam)) - 1)
+
+    lo, hi = 1e-8, 10.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if f(mid, rl, pl, al) + f(mid, rr, pr, ar) + ur - ul > 0:
+            hi = mid
+        else:
+            lo = mid
+    ps = 0.5 * (lo + hi)
+    us = 0.5 * (ul + ur) + 0.5 * (f(ps, rr, pr, ar) - f(ps, rl, pl, al))
+    rsl = rl * (ps / pl) ** (1 / gam)                    # left rarefaction
+    asl = al * (ps / pl) ** ((gam - 1) / (2 * gam))
+    rsr = rr * ((ps / pr + (gam - 1) / (gam + 1)) / ((gam - 1) / (gam + 1) * ps / pr + 1))   # right shock
+    S = ur + ar * math.sqrt((gam + 1) / (2 * gam) * ps / pr + (gam - 1) / (2 * gam))
+    rho = np.empty_like(x)
+    for i, xi in enumerate(x):
+        s = xi / t
+        if s < ul - al:
+            rho[i] = rl
+        elif s < us - asl:
+            rho[i] = rl * (2 / (gam + 1) + (gam - 1) / ((gam + 1) * al) * (ul - s)) ** (2 / (gam - 1))
+        elif s < us:
+            rho[i] = rsl
+        elif s < S:
+            rho[i] = rsr
+        else:
+            rho[i] = rr
+    return rho
+
+
+def sod_cfg(n, flux="HLLC", recon="minmod"):
+    step = lambda a, b: (lambda d: np.where(d["x"] <= 0.0, a, b))
+    return {"dim": 1, "n_cell": [n], "prob_lo": [-0.5], "prob_hi": [0.5], "is_periodic": [0], "cfl": 0.5,
+            "time_integration_scheme": "strang", "lightspeed": 1.0,
+            "states": {"gas": {"type": "hydro", "gas": {"type": "thermally_perfect", "mass": 1.0, "charge": 0.0,
+                                                         "gamma": 1.4},
+                               "reconstruction": recon, "flux": flux,
+                               "value": {"rho": step(1.0, 0.125), "x_vel": 0.0, "y_vel": 0.0, "z_vel": 0.0,
+                                         "p": step(1.0, 0.1)}}},
+            "actions": {"flux": {"type": "CTU", "corner_transport": True, "states": ["gas"]}}}
+
+
+@pytest.mark.parametrize("flux", ["HLLC", "HLLE"])
+def test_sod_against_exact_solution(oracle, flux):
+    n = 400
+    P = config.Problem(sod_cfg(n, flux))
+    sim = oracle.OracleSim(P)
+    t, dt = 0.0, sim.est_time_step()
+    while t < 0.2 - 1e-12:
+        dt = min(dt, 0.2 - t)
+        sim.advance(dt)
+        t += dt
+        dt = min(sim.est_time_step(), 1.1 * dt)
+    rho = sim.get_state(0)[0, 0, 0]
+    exact = sod_exact(P.cell_centres()["x"][0, 0], 0.2)
+    assert np.abs(rho - exact).mean() < 4e-3          # L1 error, second-order MUSCL at n = 400
+
+
+# ---- (c) structural properties -----------------------------------------------
+@pytest.mark.parametrize("case", range(5))
+def test_independent_of_box_decomposition(oracle, case):
+    """The reference runs the same stencils on every box of its BoxArray
+    (amr.max_grid_size); results cannot depend on how the level is chopped."""
+    name, cfg, steps = small_cases()[case]
+    P = config.Problem(cfg)
+    a, b = oracle.OracleSim(P), oracle.OracleSim(P, max_grid_size=8)
+    assert a.run(steps) == b.run(steps)
+    for s in range(len(P.state_names)):
+        assert np.array_equal(a.get_state(s), b.get_state(s)), (name, s)
+
+
+def test_periodic_conservation(oracle):
+    P = config.Problem(problems.kelvin_helmholtz_2d(32))
+    sim = oracle.OracleSim(P)
+    U0 = sim.get_state(0)
+    sim.run(10)
+    U1 = sim.get_state(0)
+    for c in range(5):
+        assert abs(U1[c].sum() - U0[c].sum()) <= 1e-12 * max(1.0, abs(U0[c]).sum())
+
+
+def test_ghost_fill_rules(oracle):
+    """fab_filcc semantics used for FillPatch: foextrap copies the first interior
+    cell, reflect_even mirrors, reflect_odd mirrors with a sign flip, periodic wraps;
+    corners inherit through the dimension-by-dimension sweeps."""
+    P = config.Problem(problems.gem_reconnection_2d(16, 8))   # periodic x, walls in y
+    sim = oracle.OracleSim(P)
+    s = P.state_index["ion"]
+    U = sim.get_state(s)[:, 0]
+    G = sim.fill_patch(s)[:, 0]
+    ng = 2
+    assert np.array_equal(G[:, ng:-ng, ng:-ng], U)
+    assert np.array_equal(G[:, ng:-ng, :ng], U[:, :, -ng:])                 # periodic x
+    assert np.array_equal(G[0, ng - 1, ng:-ng], U[0, 0])                    # rho: reflect_even
+    assert np.array_equal(G[0, 0, ng:-ng], U[0, 1])
+    assert np.array_equal(G[2, ng - 1, ng:-ng], -U[2, 0])                   # y momentum: reflect_odd
+    assert np.array_equal(G[1, -1, ng:-ng], U[1, -2])                       # x momentum (tangential, slipwall): even
+    assert np.array_equal(G[2, ng - 1, :ng], -U[2, 0, -ng:])                # corner: wrap in x of the reflected row
+
+
+def test_implicit_and_explicit_sources_agree_for_small_dt(oracle):
+    Pe = config.Problem(problems.orszag_tang_two_fluid_2d(16, solver="explicit"))
+    Pi = config.Problem(problems.orszag_tang_two_fluid_2d(16, solver="implicit"))
+    a, b = oracle.OracleSim(Pe), oracle.OracleSim(Pi)
+    # the Orszag-Tang start is force-free (E = -u x B / c): kick the electric field out of balance
+    f = Pe.state_index["field"]
+    F = a.get_state(f)
+    x = Pe.cell_centres()
+    F[0] += 0.01 * np.sin(x["x"])
+    F[1] += 0.02 * np.cos(x["y"])
+    F[2] += 0.015
+    a.set_state(f, F)
+    b.set_state(f, F)
+    dt = 1e-6
+    s = Pe.state_index["ion"]
+    # plasma action is index 2; first-order agreement of the momentum source
+    da, db = a.action_dU(2, dt, s), b.action_dU(2, dt, s)
+    assert np.abs(da[1:4] - db[1:4]).max() < 1e-3 * np.abs(da[1:4]).max()
