@@ -28,7 +28,8 @@ struct FaceBC {
 
 template <class Phys, int BX, int BY>
 __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
-                                                   double* __restrict__ Uout, int do_ctu, double dt, FaceBC bc, int* err) {
+                                                   double* __restrict__ Uout, int do_ctu, double dt, FaceBC bc, int* err,
+                                                   int gx, int nblk) {
     constexpr int NQ = Phys::NQ, NC = Phys::NC, NF = Phys::NF, RECON = Phys::RECON;
     constexpr int SL = ReconTraits<RECON>::SL, H = SL / 2;
     constexpr int TX = BX - 2, TY = BY - 2;
@@ -42,7 +43,13 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
 
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * BX + tx;
-    const int i0 = blockIdx.x * TX, j0 = blockIdx.y * TY;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8
+    // share one), each with its own L2.  Give every XCD a contiguous band of tile rows so
+    // that the halo overlap of neighbouring tiles is served by that XCD's L2 instead of HBM.
+    const int per = (nblk + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile >= nblk) return;
+    const int i0 = (tile % gx) * TX, j0 = (tile / gx) * TY;
     const int i = i0 - 1 + tx, j = j0 - 1 + ty;  // this thread's cell
     const int n0 = g.n[0], n1 = g.n[1];
     const double gm1 = Phys::IS_HYDRO ? Phys::gamma_of(P) - 1.0 : 0.0;
@@ -270,9 +277,10 @@ template <class Phys, int BX, int BY>
 static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhys& sp, const double* Uin, double* Uout,
                     int do_ctu, double dt, const int touches[3][2], int* err, hipStream_t st) {
     if (!Uin) return 1;  // coverage probe
-    dim3 grid((g.n[0] + BX - 3) / (BX - 2), (g.n[1] + BY - 3) / (BY - 2));
-    hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY>), grid, dim3(BX, BY), 0, st, g, P, Uin, Uout, do_ctu, dt,
-                       make_bc(sp, touches), err);
+    const int gx = (g.n[0] + BX - 3) / (BX - 2), gy = (g.n[1] + BY - 3) / (BY - 2);
+    const int nblk = gx * gy;
+    hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY>), dim3(((nblk + 7) / 8) * 8), dim3(BX, BY), 0, st, g, P, Uin, Uout, do_ctu,
+                       dt, make_bc(sp, touches), err, gx, nblk);
     return 1;
 }
 
