@@ -1,0 +1,37 @@
+"""The C++ State/Action mirror (cerberus_amd/host/MFP_host.H) drives the same C
+ABI: its demo must reproduce the Python driver's dt sequence and state sums."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cerberus_amd import abi, config, problems
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_host_demo_matches_python_driver():
+    from cerberus_amd.mfp import MFP
+    exe = os.path.join(ROOT, "cerberus_amd", "host", "host_demo")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    out = subprocess.run([exe, "32", "5"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    dts = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("dt ")]
+    sums = {l.split()[1]: (float(l.split()[3]), float(l.split()[5])) for l in out.stdout.splitlines() if l.startswith("state ")}
+    P = config.Problem(problems.orszag_tang_two_fluid_2d(32), fp_mode=abi.FP_STRICT)
+    m = MFP(P)
+    m.init_data()
+    ref_dts = m.run(5)
+    assert dts == ref_dts
+    for s, name in enumerate(P.state_names):
+        U = m.download(s)
+        # the demo accumulates in memory order with a plain loop
+        flat = U.ravel()
+        tot, sq = 0.0, 0.0
+        for v in flat.tolist():
+            tot += v
+            sq += v * v
+        assert sums[name] == (tot, sq), name
+    m.close()
