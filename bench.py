@@ -25,7 +25,7 @@ ALGO_BYTES = {"ot2f_2d": 320, "kh_2d": 80}   # 2 x 8 B x Ncomp
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def build_problem(workload, n, grid, fp_mode):
+def build_problem(workload, n, grid, fp_mode, corner_transport=True):
     from cerberus_amd import config, problems
     if workload == "ot2f_2d":
         cfg = problems.orszag_tang_two_fluid_2d(n)
@@ -33,6 +33,10 @@ def build_problem(workload, n, grid, fp_mode):
         cfg = problems.kelvin_helmholtz_2d(n)
     else:
         raise SystemExit(f"unknown workload {workload}")
+    if not corner_transport:
+        for a in cfg["actions"].values():
+            if a["type"] == "CTU":
+                a["corner_transport"] = False
     # weak scaling: the domain grows with the process grid, dx and the per-GPU block stay fixed
     # (both initial conditions are periodic with the single-GPU domain length)
     for d in range(2):
@@ -79,6 +83,7 @@ def main():
     ap.add_argument("--fp", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-corner-transport", action="store_true", help="diagnostic: corner_transport=false (not the headline workload)")
     args = ap.parse_args()
 
     import torch
@@ -100,7 +105,7 @@ def main():
 
     fp_mode = abi.FP_FAST if args.fp == "fast" else abi.FP_STRICT
     grid = block_grid(2, world)
-    P = build_problem(args.workload, args.n, grid, fp_mode)
+    P = build_problem(args.workload, args.n, grid, fp_mode, not args.no_corner_transport)
     m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=not args.no_fused)
     m.init_data()
 
@@ -162,7 +167,7 @@ def main():
             "config": {"workload": f"{args.workload} {args.n}x{args.n} per GPU "
                                    f"({'BASELINE configs[2]: 2D two-fluid Orszag-Tang, plasma5 source' if args.workload == 'ot2f_2d' else 'BASELINE configs[1]: 2D KH hydro HLLC'})",
                        "process_grid": grid[:2], "global_cells": [P.n_cell[0], P.n_cell[1]], "fp_mode": args.fp,
-                       "fused_kernels": bool(fused), "time_integration": P.scheme, "cfl": P.cfl},
+                       "fused_kernels": bool(fused), "corner_transport": not args.no_corner_transport, "time_integration": P.scheme, "cfl": P.cfl},
             "hbm_roofline_frac_whole_step": (step_bytes * args.steps / (el)) / 1e9 / HBM_PEAK_GBS,
             "roofline": roof,
             "kernel_ms_per_step": {"ctu_hydro": prof[0][1] / args.steps, "ctu_field": prof[1][1] / args.steps,

@@ -21,6 +21,19 @@
 namespace CMFP_NS {
 using namespace cmfp;
 
+#ifdef CMFP_STAMPS
+// diagnostic build only: per-phase shader cycles of wave 0 of every workgroup
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k)                                                          \
+    do {                                                                  \
+        unsigned long long t_ = __builtin_readcyclecounter();             \
+        if (tid == 0) atomicAdd(&g_stamps[k], t_ - t_prev_);              \
+        t_prev_ = t_;                                                     \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
 struct FaceBC {
     int touch[2][2];   // [d][side]: physical (non-periodic) domain face on this block
     int rule[2][2][10];  // FILL_SKIP / FILL_EVEN / FILL_ODD per primitive comp
@@ -53,6 +66,9 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
     const int i = i0 - 1 + tx, j = j0 - 1 + ty;  // this thread's cell
     const int n0 = g.n[0], n1 = g.n[1];
     const double gm1 = Phys::IS_HYDRO ? Phys::gamma_of(P) - 1.0 : 0.0;
+#ifdef CMFP_STAMPS
+    unsigned long long t_prev_ = __builtin_readcyclecounter();
+#endif
 
     // ---- phase 0: conserved -> primitives for the tile grown by 1 + H
     for (int t = tid; t < PX * PY; t += C) {
@@ -69,7 +85,9 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
             for (int n = 0; n < NQ; ++n) Pq[n * (PX * PY) + t] = Q[n];
         }
     }
+    STAMP(0);
     __syncthreads();
+    STAMP(1);
 
     // ---- phase 1: reconstruction + half-step trace of this cell, both directions
     double lo[2][NQ], hi[2][NQ];
@@ -108,7 +126,9 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
             for (int n = 0; n < NQ; ++n) bufR[(d * NQ + n) * C + tid] = hi[d][n];
         }
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
 
     // ---- phase 2: Riemann sweep 1 on the low faces of this cell
     double fx[NC] = {0}, fy[NC] = {0};
@@ -131,7 +151,9 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
             Fb[(0 * NF + n) * C + tid] = fx[n];
             Fb[(1 * NF + n) * C + tid] = fy[n];
         }
+        STAMP(4);
         __syncthreads();
+        STAMP(5);
 
         // ---- phase 3: transverse correction of this cell's face states
         // (EulerianState::correct_face_prim MFP_eulerian.cpp:1047-1188, written per cell:
@@ -167,7 +189,9 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int n = 0; n < NQ; ++n) bufR[(d * NQ + n) * C + tid] = hi[d][n];
+        STAMP(6);
         __syncthreads();
+        STAMP(7);
 
         // ---- phase 4: domain-face BCs (update_face_prim, do_all) + Riemann sweep 2
         {
@@ -215,7 +239,9 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
         Fb[(0 * NF + n) * C + tid] = fx[n];
         Fb[(1 * NF + n) * C + tid] = fy[n];
     }
+    STAMP(8);
     __syncthreads();
+    STAMP(9);
 
     // ---- phase 5: divergence (calc_divergence MFP_eulerian.cpp:1614-1662) and new += dU
     if (tx >= 1 && tx <= BX - 2 && ty >= 1 && ty <= BY - 2 && i < n0 && j < n1) {
@@ -234,6 +260,7 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
             Uout[c + n * g.sc] = Uin[c + n * g.sc] + du;
         }
     }
+    STAMP(10);
 }
 
 // physics adaptors used by the fused kernel (the staged kernels use the same
@@ -291,6 +318,16 @@ static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhy
 #ifndef CMFP_FBX
 #define CMFP_FBX 16
 #define CMFP_FBY 16
+#endif
+
+#ifdef CMFP_STAMPS
+extern "C" void cmfp_debug_stamps(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+    }
+}
 #endif
 
 int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
