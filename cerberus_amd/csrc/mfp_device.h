@@ -264,54 +264,40 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
     }
     double S_R = uR + aR * qR;
 
-    if (S_L >= 0.0) {
-        F[0] = rhoL * uL;
-        F[1] = rhoL * uL * uL + pL;
-        F[2] = rhoL * uL * vL;
-        F[3] = rhoL * uL * wL;
-        F[4] = uL * (nrgL + pL);
-    } else if ((S_L <= 0.0) && (0.0 <= S_star)) {
-        double fv0 = rhoL * uL;
-        double fv1 = rhoL * uL * uL + pL;
-        double fv2 = rhoL * uL * vL;
-        double fv3 = rhoL * uL * wL;
-        double fv4 = uL * (nrgL + pL);
-        double sv0 = rhoL, sv1 = rhoL * uL, sv2 = rhoL * vL, sv3 = rhoL * wL, sv4 = nrgL;
-        double coeff = rhoL * ((S_L - uL) / (S_L - S_star));
-        double ss0 = coeff;
-        double ss1 = coeff * S_star;
-        double ss2 = coeff * vL;
-        double ss3 = coeff * wL;
-        double ss4 = coeff * (nrgL / rhoL + (S_star - uL) * (S_star + pL / (rhoL * (S_L - uL))));
-        F[0] = fv0 + S_L * (ss0 - sv0);
-        F[1] = fv1 + S_L * (ss1 - sv1);
-        F[2] = fv2 + S_L * (ss2 - sv2);
-        F[3] = fv3 + S_L * (ss3 - sv3);
-        F[4] = fv4 + S_L * (ss4 - sv4);
-    } else if ((S_star <= 0.0) && (0.0 <= S_R)) {
-        double fv0 = rhoR * uR;
-        double fv1 = rhoR * uR * uR + pR;
-        double fv2 = rhoR * uR * vR;
-        double fv3 = rhoR * uR * wR;
-        double fv4 = uR * (nrgR + pR);
-        double sv0 = rhoR, sv1 = rhoR * uR, sv2 = rhoR * vR, sv3 = rhoR * wR, sv4 = nrgR;
-        double coeff = rhoR * ((S_R - uR) / (S_R - S_star));
-        double ss0 = coeff;
-        double ss1 = coeff * S_star;
-        double ss2 = coeff * vR;
-        double ss3 = coeff * wR;
-        double ss4 = coeff * (nrgR / rhoR + (S_star - uR) * (S_star + pR / (rhoR * (S_R - uR))));
-        F[0] = fv0 + S_R * (ss0 - sv0);
-        F[1] = fv1 + S_R * (ss1 - sv1);
-        F[2] = fv2 + S_R * (ss2 - sv2);
-        F[3] = fv3 + S_R * (ss3 - sv3);
-        F[4] = fv4 + S_R * (ss4 - sv4);
+    // The reference's four-way branch (MFP_hllc.cpp:92-184) written as a side
+    // selection: every lane evaluates the same expressions on the state of the
+    // side the branch would have used, so results are identical while a wave
+    // whose lanes fall in different branches runs one body instead of four.
+    const bool pureL = (S_L >= 0.0);
+    const bool starL = !pureL && (S_L <= 0.0) && (0.0 <= S_star);
+    const bool starR = !pureL && !starL && (S_star <= 0.0) && (0.0 <= S_R);
+    const bool useL = pureL || starL;
+    const double rho = useL ? rhoL : rhoR, u = useL ? uL : uR, v = useL ? vL : vR, w = useL ? wL : wR;
+    const double p = useL ? pL : pR, nrg = useL ? nrgL : nrgR, S_K = useL ? S_L : S_R;
+    const double fv0 = rho * u;
+    const double fv1 = rho * u * u + p;
+    const double fv2 = rho * u * v;
+    const double fv3 = rho * u * w;
+    const double fv4 = u * (nrg + p);
+    if (starL || starR) {
+        const double sv0 = rho, sv1 = rho * u, sv2 = rho * v, sv3 = rho * w, sv4 = nrg;
+        const double coeff = rho * ((S_K - u) / (S_K - S_star));
+        const double ss0 = coeff;
+        const double ss1 = coeff * S_star;
+        const double ss2 = coeff * v;
+        const double ss3 = coeff * w;
+        const double ss4 = coeff * (nrg / rho + (S_star - u) * (S_star + p / (rho * (S_K - u))));
+        F[0] = fv0 + S_K * (ss0 - sv0);
+        F[1] = fv1 + S_K * (ss1 - sv1);
+        F[2] = fv2 + S_K * (ss2 - sv2);
+        F[3] = fv3 + S_K * (ss3 - sv3);
+        F[4] = fv4 + S_K * (ss4 - sv4);
     } else {
-        F[0] = rhoR * uR;
-        F[1] = rhoR * uR * uR + pR;
-        F[2] = rhoR * uR * vR;
-        F[3] = rhoR * uR * wR;
-        F[4] = uR * (nrgR + pR);
+        F[0] = fv0;
+        F[1] = fv1;
+        F[2] = fv2;
+        F[3] = fv3;
+        F[4] = fv4;
     }
 }
 

@@ -39,7 +39,7 @@ struct FaceBC {
     int rule[2][2][10];  // FILL_SKIP / FILL_EVEN / FILL_ODD per primitive comp
 };
 
-template <class Phys, int BX, int BY>
+template <class Phys, int BX, int BY, bool HAS_BC>
 __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
                                                    double* __restrict__ Uout, int do_ctu, double dt, FaceBC bc, int* err,
                                                    int gx, int nblk) {
@@ -202,12 +202,12 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
                     L[n] = bufR[(0 * NQ + n) * C + tid - 1];
                     R[n] = lo[0][n];
                 }
-                if (bc.touch[0][0] && i == 0) {
+                if (HAS_BC && bc.touch[0][0] && i == 0) {
 #pragma unroll
                     for (int n = 0; n < NQ; ++n)
                         if (bc.rule[0][0][n]) L[n] = bc.rule[0][0][n] == FILL_ODD ? -R[n] : R[n];
                 }
-                if (bc.touch[0][1] && i == n0) {
+                if (HAS_BC && bc.touch[0][1] && i == n0) {
 #pragma unroll
                     for (int n = 0; n < NQ; ++n)
                         if (bc.rule[0][1][n]) R[n] = bc.rule[0][1][n] == FILL_ODD ? -L[n] : L[n];
@@ -220,12 +220,12 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
                     L[n] = bufR[(1 * NQ + n) * C + tid - BX];
                     R[n] = lo[1][n];
                 }
-                if (bc.touch[1][0] && j == 0) {
+                if (HAS_BC && bc.touch[1][0] && j == 0) {
 #pragma unroll
                     for (int n = 0; n < NQ; ++n)
                         if (bc.rule[1][0][n]) L[n] = bc.rule[1][0][n] == FILL_ODD ? -R[n] : R[n];
                 }
-                if (bc.touch[1][1] && j == n1) {
+                if (HAS_BC && bc.touch[1][1] && j == n1) {
 #pragma unroll
                     for (int n = 0; n < NQ; ++n)
                         if (bc.rule[1][1][n]) R[n] = bc.rule[1][1][n] == FILL_ODD ? -L[n] : L[n];
@@ -306,8 +306,13 @@ static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhy
     if (!Uin) return 1;  // coverage probe
     const int gx = (g.n[0] + BX - 3) / (BX - 2), gy = (g.n[1] + BY - 3) / (BY - 2);
     const int nblk = gx * gy;
-    hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY>), dim3(((nblk + 7) / 8) * 8), dim3(BX, BY), 0, st, g, P, Uin, Uout, do_ctu,
-                       dt, make_bc(sp, touches), err, gx, nblk);
+    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
+    if (has_bc)
+        hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, true>), dim3(((nblk + 7) / 8) * 8), dim3(BX, BY), 0, st, g, P, Uin, Uout,
+                           do_ctu, dt, make_bc(sp, touches), err, gx, nblk);
+    else
+        hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, false>), dim3(((nblk + 7) / 8) * 8), dim3(BX, BY), 0, st, g, P, Uin, Uout,
+                           do_ctu, dt, make_bc(sp, touches), err, gx, nblk);
     return 1;
 }
 
