@@ -448,7 +448,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         if (A.kind == CMFP_ACTION_CTU)
             for (int i = 0; i < A.n_states; ++i)
                 if (!c->L->ctu_fused(c->g, c->states[A.states[i]].sp, nullptr, nullptr, A.corner_transport, dt, c->touches,
-                                     nullptr, c->stream))
+                                     nullptr, nullptr, c->stream))
                     return 0;
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
@@ -462,9 +462,26 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             int r;
             if ((r = dalloc(c, &s.alt, s.sp.nc * c->g.sc))) return r;
             if ((r = fill_patch(c, A.states[i]))) return r;
+            // a hydro state no source action touches afterwards: the CTU kernel is the last writer of
+            // the step and also leaves the CFL reduction of what it wrote
+            bool reduce = s.sp.kind == CMFP_STATE_HYDRO;
+            if (src >= 0) {
+                const cmfp_action_desc& SA = c->actions[src];
+                for (int q = 0; q < SA.n_states - 1; ++q)
+                    if (SA.states[q] == A.states[i]) reduce = false;
+            }
+            unsigned long long* slots = nullptr;
+            if (reduce) {
+                slots = reinterpret_cast<unsigned long long*>(c->d_part + (size_t)A.states[i] * CMFP_RED_BLOCKS);
+                HIPCHK(c, hipMemsetAsync(slots, 0, 256 * sizeof(unsigned long long), c->stream));
+            }
             {
                 ProfScope prof(c, s.sp.kind == CMFP_STATE_HYDRO ? CMFP_PROF_CTU_HYDRO : CMFP_PROF_CTU_FIELD);
-                c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, A.corner_transport, dt, c->touches, c->d_err, c->stream);
+                c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, A.corner_transport, dt, c->touches, c->d_err, slots, c->stream);
+            }
+            if (reduce) {
+                c->L->reduce_final(reinterpret_cast<const double*>(slots), 256, 1, c->d_red + A.states[i], c->stream);
+                c->red_valid[A.states[i]] = 1;
             }
             std::swap(s.new_data, s.alt);
         }

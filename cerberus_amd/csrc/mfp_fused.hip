@@ -39,10 +39,10 @@ struct FaceBC {
     int rule[2][2][10];  // FILL_SKIP / FILL_EVEN / FILL_ODD per primitive comp
 };
 
-template <class Phys, int BX, int BY, bool HAS_BC>
+template <class Phys, int BX, int BY, bool HAS_BC, bool REDUCE>
 __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
                                                    double* __restrict__ Uout, int do_ctu, double dt, FaceBC bc, int* err,
-                                                   int gx, int nblk) {
+                                                   int gx, int nblk, unsigned long long* red) {
     constexpr int NQ = Phys::NQ, NC = Phys::NC, NF = Phys::NF, RECON = Phys::RECON;
     constexpr int SL = ReconTraits<RECON>::SL, H = SL / 2;
     constexpr int TX = BX - 2, TY = BY - 2;
@@ -243,10 +243,12 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
     __syncthreads();
     STAMP(9);
 
+    double red_speed = 2.2250738585072014e-308;  // std::numeric_limits<Real>::min(), MFP_eulerian.cpp:265
     // ---- phase 5: divergence (calc_divergence MFP_eulerian.cpp:1614-1662) and new += dU
     if (tx >= 1 && tx <= BX - 2 && ty >= 1 && ty <= BY - 2 && i < n0 && j < n1) {
         const long c = g.at(i, j, 0);
         const double dtdx = dt / g.dx[0], dtdy = dt / g.dx[1];
+        double Unew[NC];
 #pragma unroll
         for (int n = 0; n < NC; ++n) {
             double du = 0.0;
@@ -257,7 +259,31 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
                 du += dtdx * (0.0 - 0.0);
                 du += dtdy * (0.0 - 0.0);
             }
-            Uout[c + n * g.sc] = Uin[c + n * g.sc] + du;
+            Unew[n] = Uin[c + n * g.sc] + du;
+            Uout[c + n * g.sc] = Unew[n];
+        }
+        if constexpr (Phys::IS_HYDRO && REDUCE) {
+            {  // EulerianState::get_allowed_time_step MFP_eulerian.cpp:290-296 on the values just written
+                double s[3];
+                hydro_speed_from_cons(P.gas, Unew, s);
+                red_speed = std_max(std_max(red_speed, s[0]), s[1]);
+            }
+        }
+    }
+    if constexpr (Phys::IS_HYDRO && REDUCE) {
+        {
+            // CFL reduction fused into the last kernel that writes this state: wave max,
+            // workgroup max through LDS, then one 64-bit integer atomic per workgroup on one of
+            // 256 slots (positive doubles order like their bit patterns)
+            double* const shr = bufR;  // free since the barrier that ended phase 4
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) red_speed = fmax(red_speed, __shfl_xor(red_speed, o, 64));
+            if ((tid & 63) == 0) shr[tid >> 6] = red_speed;
+            __syncthreads();
+            if (tid == 0) {
+                for (int w2 = 1; w2 < C / 64; ++w2) red_speed = fmax(red_speed, shr[w2]);
+                atomicMax(&red[tile & 255], (unsigned long long)__double_as_longlong(red_speed));
+            }
         }
     }
     STAMP(10);
@@ -302,17 +328,24 @@ static FaceBC make_bc(const StatePhys& sp, const int touches[3][2]) {
 
 template <class Phys, int BX, int BY>
 static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhys& sp, const double* Uin, double* Uout,
-                    int do_ctu, double dt, const int touches[3][2], int* err, hipStream_t st) {
+                    int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
     if (!Uin) return 1;  // coverage probe
     const int gx = (g.n[0] + BX - 3) / (BX - 2), gy = (g.n[1] + BY - 3) / (BY - 2);
     const int nblk = gx * gy;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
-    if (has_bc)
-        hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, true>), dim3(((nblk + 7) / 8) * 8), dim3(BX, BY), 0, st, g, P, Uin, Uout,
-                           do_ctu, dt, make_bc(sp, touches), err, gx, nblk);
-    else
-        hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, false>), dim3(((nblk + 7) / 8) * 8), dim3(BX, BY), 0, st, g, P, Uin, Uout,
-                           do_ctu, dt, make_bc(sp, touches), err, gx, nblk);
+    const dim3 grid(((nblk + 7) / 8) * 8), block(BX, BY);
+    const FaceBC bc = make_bc(sp, touches);
+#define CMFP_LAUNCH(BC, RED)                                                                                          \
+    hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, BC, RED>), grid, block, 0, st, g, P, Uin, Uout, do_ctu, dt, bc, err, gx, \
+                       nblk, red)
+    if constexpr (Phys::IS_HYDRO) {
+        if (red) {
+            if (has_bc) CMFP_LAUNCH(true, true); else CMFP_LAUNCH(false, true);
+            return 1;
+        }
+    }
+    if (has_bc) CMFP_LAUNCH(true, false); else CMFP_LAUNCH(false, false);
+#undef CMFP_LAUNCH
     return 1;
 }
 
@@ -336,13 +369,13 @@ extern "C" void cmfp_debug_stamps(unsigned long long* out, int reset) {
 #endif
 
 int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
-              const int touches[3][2], int* err, hipStream_t st) {
+              const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
     if (g.dim != 2) return 0;
 #define HY(R, F)                                                                                                    \
     if (sp.recon == R && sp.flux == F)                                                                              \
-        return launch2d<HydroF<R, F>, CMFP_HBX, CMFP_HBY>(g, sp.hp, sp, Uin, Uout, do_ctu, dt, touches, err, st);
+        return launch2d<HydroF<R, F>, CMFP_HBX, CMFP_HBY>(g, sp.hp, sp, Uin, Uout, do_ctu, dt, touches, err, red, st);
 #define FI(R)                                                                                                       \
-    if (sp.recon == R) return launch2d<FieldF<R>, CMFP_FBX, CMFP_FBY>(g, sp.fp, sp, Uin, Uout, do_ctu, dt, touches, err, st);
+    if (sp.recon == R) return launch2d<FieldF<R>, CMFP_FBX, CMFP_FBY>(g, sp.fp, sp, Uin, Uout, do_ctu, dt, touches, err, red, st);
     if (sp.kind == 0) {
         HY(1, 0) HY(1, 1) HY(1, 2) HY(2, 0) HY(2, 1) HY(2, 2) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)
     } else {

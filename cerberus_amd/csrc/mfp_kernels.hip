@@ -978,14 +978,17 @@ static int l_leaf_prim2cons(long n, double mass, double gamma, const double* Q, 
 
 // defined in mfp_fused.hip
 int ctu_fused(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
-              const int touches[3][2], int* err, hipStream_t);
+              const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
+static void l_reduce_final(const double* part, int n, int is_max, unsigned long long* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, part, n, is_max, out);
+}
 
 const Launchers* launchers() {
     static const Launchers L = {l_prim,      l_recon,         l_face_bc,        l_fluxes,          l_correct,
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_fill_dim,        l_pack,
                                 ctu_fused,   l_source_fused,  l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
-                                l_leaf_prim2cons};
+                                l_leaf_prim2cons, l_reduce_final};
     return &L;
 }
 

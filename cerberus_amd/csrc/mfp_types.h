@@ -115,7 +115,7 @@ struct Launchers {
     void (*pack)(const Geo&, int nc, int ngs, double* A, int d, int side, double* buf, int unpack, hipStream_t);
     // fused paths (return 0 when the option set is not covered)
     int (*ctu_fused)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
-                     const int touches[3][2], int* err, hipStream_t);
+                     const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
     int (*source_fused)(const Geo&, const SourceArgs&, double dt, int reduce, hipStream_t);
     // batched leaves
     int (*leaf_reconstruct)(int recon, long n, const double* st, double* slope, double* lo, double* hi, hipStream_t);
@@ -123,6 +123,7 @@ struct Launchers {
                         double thr, hipStream_t);
     int (*leaf_cons2prim)(long n, double mass, double gamma, const double* U, double* Q, double* sp, hipStream_t);
     int (*leaf_prim2cons)(long n, double mass, double gamma, const double* Q, double* U, hipStream_t);
+    void (*reduce_final)(const double* part, int n, int is_max, unsigned long long* out, hipStream_t);
 };
 
 }  // namespace cmfp
