@@ -30,6 +30,43 @@ CMFP_DEV double tanh_approx(double x) {
     if (x <= -1.92033) return -0.96016;
     return 0.26037 * (x + 1.92033) * (x + 1.92033) - 0.96016;
 }
+// Division / square root.  STRICT: the IEEE operations, as the reference's host build.  FAST
+// (-DCMFP_FASTMATH): hardware seed (v_rcp_f64 / v_rsq_f64, 2^-24 relative) + two Newton steps
+// for the reciprocal, one coupled step + a residual correction for the root: measured <= 1.2e-16
+// relative on 4 M random arguments (tools/fastmath_probe.hip); 5 and 8 instructions instead of
+// the compiler's 9 and ~20 (range scaling for denormal arguments that this path never sees).
+#ifdef CMFP_FASTMATH
+CMFP_DEV double f_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(e, r, r);
+    e = fma(-x, r, 1.0);
+    return fma(e, r, r);
+}
+CMFP_DEV double f_div(double a, double b) { return a * f_rcp(b); }
+CMFP_DEV double f_sqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return (x == 0.0) ? 0.0 : g;
+}
+// 1 / sqrt(x): seed + one step with the quadratic term (e = 1 - x y^2 ~ 2^-23, e^3 is below an ulp)
+CMFP_DEV double f_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-(x * y), y, 1.0);
+    double t = fma(0.375, e, 0.5);
+    return fma(y * e, t, y);
+}
+#else
+CMFP_DEV double f_rsqrt(double x) { return 1 / sqrt(x); }
+CMFP_DEV double f_rcp(double x) { return 1 / x; }
+CMFP_DEV double f_div(double a, double b) { return a / b; }
+CMFP_DEV double f_sqrt(double x) { return sqrt(x); }
+#endif
 // std::min / std::max semantics (return the first argument on ties / NaN)
 CMFP_DEV double std_min(double a, double b) { return (b < a) ? b : a; }
 CMFP_DEV double std_max(double a, double b) { return (a < b) ? b : a; }
@@ -181,7 +218,7 @@ using cmfp::GasP;
 // reference aborts).
 CMFP_DEV bool hydro_cons2prim(const GasP& G, const double* U, double* Q) {
     double rho = U[0], mx = U[1], my = U[2], mz = U[3], ed = U[4];
-    double rhoinv = 1 / rho;
+    double rhoinv = f_rcp(rho);
     double u = mx * rhoinv;
     double v = my * rhoinv;
     double w = mz * rhoinv;
@@ -204,7 +241,7 @@ CMFP_DEV void hydro_prim2cons(const GasP& G, const double* Q, double* U) {
     double mz = w * rho;
     double ke = 0.5 * rho * (u * u + v * v + w * w);
     double g = G.gamma;
-    double ed = p / (g - 1) + ke;
+    double ed = f_div(p, g - 1) + ke;
     U[0] = rho;
     U[1] = mx;
     U[2] = my;
@@ -214,21 +251,21 @@ CMFP_DEV void hydro_prim2cons(const GasP& G, const double* Q, double* U) {
 // ThermallyPerfectGas::get_speed_from_cons :294-317
 CMFP_DEV void hydro_speed_from_cons(const GasP& G, const double* U, double* s) {
     double rho = U[0], mx = U[1], my = U[2], mz = U[3], ed = U[4];
-    double rhoinv = 1 / rho;
+    double rhoinv = f_rcp(rho);
     double u = mx * rhoinv;
     double v = my * rhoinv;
     double w = mz * rhoinv;
     double ke = 0.5 * rho * (u * u + v * v + w * w);
     double g = G.gamma;
     double p = (ed - ke) * (g - 1);
-    double a = sqrt(g * p * rhoinv);
+    double a = f_sqrt(g * p * rhoinv);
     s[0] = a + fabs(u);
     s[1] = a + fabs(v);
     s[2] = a + fabs(w);
 }
 // ThermallyPerfectGas::get_speed_from_prim :319-332
 CMFP_DEV void hydro_speed_from_prim(const GasP& G, const double* Q, double* s) {
-    double a = sqrt(G.gamma * Q[H_P] / Q[H_RHO]);
+    double a = f_sqrt(f_div(G.gamma * Q[H_P], Q[H_RHO]));
     s[0] = a + fabs(Q[H_U]);
     s[1] = a + fabs(Q[H_V]);
     s[2] = a + fabs(Q[H_W]);
@@ -238,29 +275,35 @@ CMFP_DEV void hydro_speed_from_prim(const GasP& G, const double* Q, double* s) {
 // HydroHLLC::solve MFP_hllc.cpp:30-185.  L, R in the face-normal frame.
 CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double gamR, double* F) {
     double rhoL = L[H_RHO], uL = L[H_U], vL = L[H_V], wL = L[H_W], pL = L[H_P];
-    double nrgL = pL / (gamL - 1) + 0.5 * rhoL * (uL * uL + vL * vL + wL * wL);
-    double aL = sqrt(gamL * pL / rhoL);
+    double nrgL = f_div(pL, gamL - 1) + 0.5 * rhoL * (uL * uL + vL * vL + wL * wL);
     double rhoR = R[H_RHO], uR = R[H_U], vR = R[H_V], wR = R[H_W], pR = R[H_P];
-    double nrgR = pR / (gamR - 1) + 0.5 * rhoR * (uR * uR + vR * vR + wR * wR);
-    double aR = sqrt(gamR * pR / rhoR);
+    double nrgR = f_div(pR, gamR - 1) + 0.5 * rhoR * (uR * uR + vR * vR + wR * wR);
+#ifdef CMFP_FASTMATH
+    const double rinvL = f_rcp(rhoL), rinvR = f_rcp(rhoR);  // reused for nrg / rho of the chosen side below
+    double aL = f_sqrt(gamL * pL * rinvL);
+    double aR = f_sqrt(gamR * pR * rinvR);
+#else
+    double aL = f_sqrt(f_div(gamL * pL, rhoL));
+    double aR = f_sqrt(f_div(gamR * pR, rhoR));
+#endif
 
     double rho_bar = 0.5 * (rhoL + rhoR);
     double a_bar = 0.5 * (aL + aR);
     double p_star = 0.5 * (pL + pR) - 0.5 * (uR - uL) * rho_bar * a_bar;
-    double S_star = 0.5 * (uL + uR) - 0.5 * (pR - pL) / (rho_bar * a_bar);
+    double S_star = 0.5 * (uL + uR) - f_div(0.5 * (pR - pL), rho_bar * a_bar);
 
     double qL;
     if (p_star <= pL) {
         qL = 1.0;
     } else {
-        qL = sqrt(1.0 + ((gamL + 1.0) / (2 * gamL)) * (p_star / pL - 1.0));
+        qL = f_sqrt(1.0 + f_div(gamL + 1.0, 2 * gamL) * (f_div(p_star, pL) - 1.0));
     }
     double S_L = uL - aL * qL;
     double qR;
     if (p_star <= pR) {
         qR = 1.0;
     } else {
-        qR = sqrt(1.0 + ((gamR + 1.0) / (2 * gamR)) * (p_star / pR - 1.0));
+        qR = f_sqrt(1.0 + f_div(gamR + 1.0, 2 * gamR) * (f_div(p_star, pR) - 1.0));
     }
     double S_R = uR + aR * qR;
 
@@ -281,12 +324,17 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
     const double fv4 = u * (nrg + p);
     if (starL || starR) {
         const double sv0 = rho, sv1 = rho * u, sv2 = rho * v, sv3 = rho * w, sv4 = nrg;
-        const double coeff = rho * ((S_K - u) / (S_K - S_star));
+        const double coeff = rho * f_div(S_K - u, S_K - S_star);
         const double ss0 = coeff;
         const double ss1 = coeff * S_star;
         const double ss2 = coeff * v;
         const double ss3 = coeff * w;
-        const double ss4 = coeff * (nrg / rho + (S_star - u) * (S_star + p / (rho * (S_K - u))));
+#ifdef CMFP_FASTMATH
+        const double nrg_rho = nrg * (useL ? rinvL : rinvR);
+#else
+        const double nrg_rho = f_div(nrg, rho);
+#endif
+        const double ss4 = coeff * (nrg_rho + (S_star - u) * (S_star + f_div(p, rho * (S_K - u))));
         F[0] = fv0 + S_K * (ss0 - sv0);
         F[1] = fv1 + S_K * (ss1 - sv1);
         F[2] = fv2 + S_K * (ss2 - sv2);
@@ -304,11 +352,11 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
 // HydroHLLE::solve MFP_hydro_hlle.cpp:30-120
 CMFP_DEV void hlle_solve(const double* L, const double* R, double gamL, double gamR, double* F) {
     double rhoL = L[H_RHO], uL = L[H_U], vL = L[H_V], wL = L[H_W], pL = L[H_P];
-    double nrgL = pL / (gamL - 1) + 0.5 * rhoL * (uL * uL + vL * vL + wL * wL);
-    double aL = sqrt(gamL * pL / rhoL);
+    double nrgL = f_div(pL, gamL - 1) + 0.5 * rhoL * (uL * uL + vL * vL + wL * wL);
+    double aL = f_sqrt(f_div(gamL * pL, rhoL));
     double rhoR = R[H_RHO], uR = R[H_U], vR = R[H_V], wR = R[H_W], pR = R[H_P];
-    double nrgR = pR / (gamR - 1) + 0.5 * rhoR * (uR * uR + vR * vR + wR * wR);
-    double aR = sqrt(gamR * pR / rhoR);
+    double nrgR = f_div(pR, gamR - 1) + 0.5 * rhoR * (uR * uR + vR * vR + wR * wR);
+    double aR = f_sqrt(f_div(gamR * pR, rhoR));
 
     double sL = std_min(uL - aL, uR - aR);
     double sR = std_max(uL + aL, uR + aR);
@@ -342,7 +390,7 @@ CMFP_DEV void hlle_solve(const double* L, const double* R, double gamL, double g
         sRv[3] = rhoR * wR;
         sRv[4] = nrgR;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { F[i] = (sR * fL[i] - sL * fR[i] + sL * sR * (sRv[i] - sLv[i])) / (sR - sL); }
+        for (int i = 0; i < 5; ++i) { F[i] = f_div(sR * fL[i] - sL * fR[i] + sL * sR * (sRv[i] - sLv[i]), sR - sL); }
     } else {
         F[0] = rhoR * uR;
         F[1] = rhoR * uR * uR + pR;
@@ -400,10 +448,32 @@ CMFP_DEV void field_rh_solve(double c0, double ch, const double* L, const double
     double epr = R[F_EP], epl = L[F_EP];
     double Bl = L[F_BZ], Br = R[F_BZ];
     double mur = R[F_MU], mul = L[F_MU];
-    double cr = 1 / sqrt(mur * epr);
-    double cl = 1 / sqrt(mul * epl);
-    F[F_DY] = c0 * ((Bl * cl + Br * cr) + (Dl / epl - Dr / epr)) / (cl * mul + cr * mur);
-    F[F_BZ] = c0 * ((Dl * cl + Dr * cr) + (Bl / mul - Br / mur)) / (cl * epl + cr * epr);
+    if (mul == 1.0 && epl == 1.0 && mur == 1.0 && epr == 1.0) {
+        // vacuum on both sides: the general expressions below evaluate to exactly these values
+        // (c = 1/sqrt(1) = 1, x/1 = x, division by 2 is exact), with no division or root
+        const double hc = 0.5 * c0;
+        F[F_DY] = (c0 * ((Bl + Br) + (Dl - Dr))) * 0.5;
+        F[F_BZ] = (c0 * ((Dl + Dr) + (Bl - Br))) * 0.5;
+        Dl = L[F_DZ];
+        Dr = R[F_DZ];
+        Bl = L[F_BY];
+        Br = R[F_BY];
+        F[F_DZ] = (c0 * (-(Bl + Br) + (Dl - Dr))) * 0.5;
+        F[F_BY] = (c0 * (-(Dl + Dr) + (Bl - Br))) * 0.5;
+        if (ch > 0) {
+            double Pl = L[F_PHI], Pr = R[F_PHI], fl = L[F_DX], fr = R[F_DX];
+            F[F_DX] = hc * (Pr + Pl) - 0.5 * ch * (fr - fl);
+            F[F_PHI] = 0.5 * ch2 / c0 * (fr + fl) - 0.5 * ch * (Pr - Pl);
+            Pl = L[F_PSI], Pr = R[F_PSI], fl = L[F_BX], fr = R[F_BX];
+            F[F_BX] = hc * (Pr + Pl) - 0.5 * ch * (fr - fl);
+            F[F_PSI] = 0.5 * ch2 / c0 * (fr + fl) - 0.5 * ch * (Pr - Pl);
+        }
+        return;
+    }
+    double cr = f_rsqrt(mur * epr);
+    double cl = f_rsqrt(mul * epl);
+    F[F_DY] = f_div(c0 * ((Bl * cl + Br * cr) + (f_div(Dl, epl) - f_div(Dr, epr))), cl * mul + cr * mur);
+    F[F_BZ] = f_div(c0 * ((Dl * cl + Dr * cr) + (f_div(Bl, mul) - f_div(Br, mur))), cl * epl + cr * epr);
     if (ch > 0) {
         double Pl = L[F_PHI], Pr = R[F_PHI], fl = L[F_DX], fr = R[F_DX];
         F[F_DX] = 0.5 * c0 * (Pr + Pl) - 0.5 * ch * (fr - fl);
@@ -413,8 +483,8 @@ CMFP_DEV void field_rh_solve(double c0, double ch, const double* L, const double
     Dr = R[F_DZ];
     Bl = L[F_BY];
     Br = R[F_BY];
-    F[F_DZ] = c0 * (-(Bl * cl + Br * cr) + (Dl / epl - Dr / epr)) / (cl * mul + cr * mur);
-    F[F_BY] = c0 * (-(Dl * cl + Dr * cr) + (Bl / mul - Br / mur)) / (cl * epl + cr * epr);
+    F[F_DZ] = f_div(c0 * (-(Bl * cl + Br * cr) + (f_div(Dl, epl) - f_div(Dr, epr))), cl * mul + cr * mur);
+    F[F_BY] = f_div(c0 * (-(Dl * cl + Dr * cr) + (f_div(Bl, mul) - f_div(Br, mur))), cl * epl + cr * epr);
     if (ch > 0) {
         double Pl = L[F_PSI], Pr = R[F_PSI], fl = L[F_BX], fr = R[F_BX];
         F[F_BX] = 0.5 * c0 * (Pr + Pl) - 0.5 * ch * (fr - fl);
@@ -562,25 +632,25 @@ CMFP_DEV void hydro_cell_faces(const double gamma, const double (*st)[5], double
         phi_w = 0.0;
         phi_eps = 0.0;
     } else {
-        double coeff_eps = (rho / (rho_lo * rho_hi)) * eps_face;
+        double coeff_eps = f_div(rho, rho_lo * rho_hi) * eps_face;
         if ((0.125 * abs_phi) > coeff_eps) {
-            double phi_scale = sqrt(abs_phi);
-            coeff_eps = sqrt(8 * coeff_eps);
-            phi_u = (phi_u / phi_scale) * coeff_eps;
-            phi_v = (phi_v / phi_scale) * coeff_eps;
-            phi_w = (phi_w / phi_scale) * coeff_eps;
+            double phi_scale = f_sqrt(abs_phi);
+            coeff_eps = f_sqrt(8 * coeff_eps);
+            phi_u = f_div(phi_u, phi_scale) * coeff_eps;
+            phi_v = f_div(phi_v, phi_scale) * coeff_eps;
+            phi_w = f_div(phi_w, phi_scale) * coeff_eps;
         }
         abs_phi = phi_u * phi_u + phi_v * phi_v + phi_w * phi_w;
-        eps -= (rho_lo * rho_hi / rho) * 0.125 * abs_phi;
+        eps -= f_div(rho_lo * rho_hi, rho) * 0.125 * abs_phi;
     }
     lo[H_RHO] = rho_lo;
     hi[H_RHO] = rho_hi;
-    lo[H_U] = u - 0.5 * (rho_hi / rho) * phi_u;
-    hi[H_U] = u + 0.5 * (rho_lo / rho) * phi_u;
-    lo[H_V] = v - 0.5 * (rho_hi / rho) * phi_v;
-    hi[H_V] = v + 0.5 * (rho_lo / rho) * phi_v;
-    lo[H_W] = w - 0.5 * (rho_hi / rho) * phi_w;
-    hi[H_W] = w + 0.5 * (rho_lo / rho) * phi_w;
+    lo[H_U] = u - 0.5 * f_div(rho_hi, rho) * phi_u;
+    hi[H_U] = u + 0.5 * f_div(rho_lo, rho) * phi_u;
+    lo[H_V] = v - 0.5 * f_div(rho_hi, rho) * phi_v;
+    hi[H_V] = v + 0.5 * f_div(rho_lo, rho) * phi_v;
+    lo[H_W] = w - 0.5 * f_div(rho_hi, rho) * phi_w;
+    hi[H_W] = w + 0.5 * f_div(rho_lo, rho) * phi_w;
     lo[H_P] = (eps - 0.5 * phi_eps) * (gamma - 1.0);
     hi[H_P] = (eps + 0.5 * phi_eps) * (gamma - 1.0);
 }

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
 #pragma unroll
             for (int n = 0; n < NC; ++n) U[n] = Uin[c + n * g.sc];
             if (!Phys::cons2prim(P, U, Q)) *err = 1;
-            if (Phys::IS_HYDRO) Q[H_P] = Q[H_P] / gm1;  // eps = p / (gamma - 1), MFP_hydro.cpp:847-862
+            if (Phys::IS_HYDRO) Q[H_P] = f_div(Q[H_P], gm1);  // eps = p / (gamma - 1), MFP_hydro.cpp:847-862
 #pragma unroll
             for (int n = 0; n < NQ; ++n) Pq[n * (PX * PY) + t] = Q[n];
         }
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
     {
         const int pc = (ty + H) * PX + (tx + H);
         double centre[NQ], speed[3];
+        unsigned flat = 0;  // FAST mode, field: (direction, component) pairs whose stencil is flat
 #pragma unroll
         for (int n = 0; n < NQ; ++n) centre[n] = Pq[n * (PX * PY) + pc];
         if (Phys::IS_HYDRO) centre[H_P] = centre[H_P] * gm1;  // restored pressure, MFP_hydro.cpp:1025-1035
@@ -114,13 +115,30 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
                     double st[SL];
 #pragma unroll
                     for (int s = 0; s < SL; ++s) st[s] = Pq[n * (PX * PY) + pc + (s - H) * sd];
+#ifdef CMFP_FASTMATH
+                    // FAST mode: the material coefficients mu, ep never change (F = 0, no source);
+                    // where their stencil is flat the face values are the cell value itself (the
+                    // weights sum to one; the STRICT evaluation gives 1 + 2^-52 for O6) and the
+                    // trace below is the identity, so the Riemann solver sees exact vacuum values.
+                    if (n >= F_MU) {
+                        bool same = true;
+#pragma unroll
+                        for (int s = 0; s < SL; ++s) same = same && (st[s] == st[H]);
+                        if (same) {
+                            lo[d][n] = hi[d][n] = st[H];
+                            flat |= 1u << (d * 16 + n);
+                            continue;
+                        }
+                    }
+#endif
                     recon_faces<RECON>(st, lo[d][n], hi[d][n]);
                 }
             }
             if (do_ctu) {
                 const double dt_2dx = 0.5 * dt / g.dx[d];
 #pragma unroll
-                for (int n = 0; n < NQ; ++n) trace_faces(speed[d], dt_2dx, centre[n], lo[d][n], hi[d][n]);
+                for (int n = 0; n < NQ; ++n)
+                    if (!((flat >> (d * 16 + n)) & 1u)) trace_faces(speed[d], dt_2dx, centre[n], lo[d][n], hi[d][n]);
             }
 #pragma unroll
             for (int n = 0; n < NQ; ++n) bufR[(d * NQ + n) * C + tid] = hi[d][n];
