@@ -21,7 +21,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES = {"ot2f_2d": 320, "kh_2d": 80}   # 2 x 8 B x Ncomp per cell-update
+ALGO_BYTES = {"ot2f_2d": 320, "kh_2d": 80, "rmi_3d": 320}   # 2 x 8 B x Ncomp per cell-update
+WORKLOAD_NOTE = {"ot2f_2d": "BASELINE configs[2]: 2D two-fluid Orszag-Tang, plasma5 source",
+                 "kh_2d": "BASELINE configs[1]: 2D KH hydro HLLC",
+                 "rmi_3d": "BASELINE configs[4]: 3D two-fluid Richtmyer-Meshkov, plasma5 source"}
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -31,6 +34,8 @@ def build_problem(workload, n, grid, fp_mode, corner_transport=True):
         cfg = problems.orszag_tang_two_fluid_2d(n)
     elif workload == "kh_2d":
         cfg = problems.kelvin_helmholtz_2d(n)
+    elif workload == "rmi_3d":
+        cfg = problems.richtmyer_meshkov_3d(n)
     else:
         raise SystemExit(f"unknown workload {workload}")
     if not corner_transport:
@@ -39,7 +44,7 @@ def build_problem(workload, n, grid, fp_mode, corner_transport=True):
                 a["corner_transport"] = False
     # weak scaling: the domain grows with the process grid, dx and the per-GPU block stay fixed
     # (both initial conditions are periodic with the single-GPU domain length)
-    for d in range(2):
+    for d in range(cfg["dim"]):
         L = cfg["prob_hi"][d] - cfg["prob_lo"][d]
         cfg["n_cell"][d] = n * grid[d]
         cfg["prob_hi"][d] = cfg["prob_lo"][d] + L * grid[d]
@@ -104,7 +109,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     fp_mode = abi.FP_FAST if args.fp == "fast" else abi.FP_STRICT
-    grid = block_grid(2, world)
+    dim = 3 if args.workload == "rmi_3d" else 2
+    grid = block_grid(dim, world)
     P = build_problem(args.workload, args.n, grid, fp_mode, not args.no_corner_transport)
     m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=not args.no_fused)
     m.init_data()
@@ -133,7 +139,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
 
-    cells_per_gpu = args.n * args.n
+    cells_per_gpu = args.n ** dim
     total_cells = cells_per_gpu * world
     value = total_cells * args.steps / el
 
@@ -159,14 +165,13 @@ def main():
                     "launches": launches}
         step_bytes = ALGO_BYTES[args.workload] * cells_per_gpu
         out = {
-            "metric": "cell-updates/s (fp64, five-moment 2-fluid+Maxwell)" if args.workload == "ot2f_2d"
-                      else "cell-updates/s (fp64, single-fluid hydro)",
+            "metric": "cell-updates/s (fp64, single-fluid hydro)" if args.workload == "kh_2d"
+                      else "cell-updates/s (fp64, five-moment 2-fluid+Maxwell)",
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload} {args.n}x{args.n} per GPU "
-                                   f"({'BASELINE configs[2]: 2D two-fluid Orszag-Tang, plasma5 source' if args.workload == 'ot2f_2d' else 'BASELINE configs[1]: 2D KH hydro HLLC'})",
-                       "process_grid": grid[:2], "global_cells": [P.n_cell[0], P.n_cell[1]], "fp_mode": args.fp,
+            "config": {"workload": f"{args.workload} {'x'.join([str(args.n)] * dim)} per GPU ({WORKLOAD_NOTE[args.workload]})",
+                       "process_grid": grid[:dim], "global_cells": list(P.n_cell[:dim]), "fp_mode": args.fp,
                        "fused_kernels": bool(fused), "corner_transport": not args.no_corner_transport, "time_integration": P.scheme, "cfl": P.cfl},
             "hbm_roofline_frac_whole_step": (step_bytes * args.steps / (el)) / 1e9 / HBM_PEAK_GBS,
             "roofline": roof,

@@ -67,7 +67,9 @@ struct cmfp_context {
     std::vector<StateRT> states;
     std::vector<cmfp_action_desc> actions;
     int nsteps = 2;
-    int fused = 1;
+    int fused = 1;                        // 0 staged, 1 fused (2-D: tiled kernel, else gather kernels), 2 gather kernels
+    double* gF1[3] = {nullptr, nullptr, nullptr};  // face-flux scratch of the gather kernels, shared by all states
+    double* gF2[3] = {nullptr, nullptr, nullptr};
     int touches[3][2];   // block face is a non-periodic physical boundary
     int split[3];        // domain is split between ranks along d
     cmfp_exchange_fn exchange = nullptr;
@@ -443,13 +445,30 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         }
     }
     if (n_src > 1) return 0;
-    // probe coverage of the fused CTU kernel (null launch)
+    // probe coverage (null launches): the tiled 2-D kernel where it applies, else the gather kernels
+    std::vector<char> tiled(c->states.size(), 0);
+    bool any_gather = false;
+    const Ptr3 none{{nullptr, nullptr, nullptr}};
     for (const auto& A : c->actions)
         if (A.kind == CMFP_ACTION_CTU)
-            for (int i = 0; i < A.n_states; ++i)
-                if (!c->L->ctu_fused(c->g, c->states[A.states[i]].sp, nullptr, nullptr, A.corner_transport, dt, c->touches,
-                                     nullptr, nullptr, c->stream))
+            for (int i = 0; i < A.n_states; ++i) {
+                const StatePhys& sp = c->states[A.states[i]].sp;
+                if (c->fused != 2 && c->L->ctu_fused(c->g, sp, nullptr, nullptr, A.corner_transport, dt, c->touches, nullptr,
+                                                     nullptr, c->stream)) {
+                    tiled[A.states[i]] = 1;
+                } else if (c->L->ctu_gather(c->g, sp, nullptr, nullptr, none, none, A.corner_transport, dt, c->touches,
+                                            nullptr, nullptr, c->stream)) {
+                    any_gather = true;
+                } else {
                     return 0;
+                }
+            }
+    if (any_gather)
+        for (int d = 0; d < c->g.dim; ++d) {
+            int r;
+            if ((r = dalloc(c, &c->gF1[d], 8 * c->g.sc))) return r;
+            if ((r = dalloc(c, &c->gF2[d], 8 * c->g.sc))) return r;
+        }
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
         ProfScope prof(c, CMFP_PROF_SOURCE);
@@ -477,7 +496,13 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             }
             {
                 ProfScope prof(c, s.sp.kind == CMFP_STATE_HYDRO ? CMFP_PROF_CTU_HYDRO : CMFP_PROF_CTU_FIELD);
-                c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, A.corner_transport, dt, c->touches, c->d_err, slots, c->stream);
+                if (tiled[A.states[i]]) {
+                    c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, A.corner_transport, dt, c->touches, c->d_err, slots, c->stream);
+                } else {
+                    const Ptr3 F1{{c->gF1[0], c->gF1[1], c->gF1[2]}}, F2{{c->gF2[0], c->gF2[1], c->gF2[2]}};
+                    c->L->ctu_gather(c->g, s.sp, s.new_data, s.alt, F1, F2, A.corner_transport, dt, c->touches, c->d_err, slots,
+                                     c->stream);
+                }
             }
             if (reduce) {
                 c->L->reduce_final(reinterpret_cast<const double*>(slots), 256, 1, c->d_red + A.states[i], c->stream);
@@ -495,7 +520,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         for (int n = 0; n < A.n_states - 1; ++n) c->red_valid[A.states[n]] = 1;
         if (a.limits_dt) c->red_valid[c->states.size() + src] = 1;
     }
-    return 1;
+    return any_gather ? 2 : 1;
 }
 
 int check_ctx(cmfp_context* c) {
@@ -563,6 +588,9 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     g.sj = g.ext[0];
     g.sk = (long)g.ext[0] * g.ext[1];
     g.sc = g.sk * g.ext[2];
+    // kernels address inside a component plane with 32-bit byte offsets
+    if (g.sc * (long)sizeof(double) >= (1L << 32))
+        return fail(c, CMFP_ERR_INVALID, "block too large: one ghosted component plane must stay below 4 GiB (2^29 cells)");
 
     c->states.resize(n_states);
     for (int s = 0; s < n_states; ++s) {
@@ -861,8 +889,8 @@ int cmfp_advance(cmfp_context* c, double, double dt) {
     if (c->fused) {
         r = advance_strang_fused(c, dt);
         if (r < 0) return r;
-        if (r == 1) {
-            c->last_fused = 1;
+        if (r >= 1) {
+            c->last_fused = r;  // 1: tiled kernels only, 2: gather kernels used
             return CMFP_OK;
         }
     }

@@ -665,4 +665,28 @@ CMFP_DEV void trace_faces(double c, double dt_2dx, double centre, double& lo, do
     hi -= c * dt_2dx * (hi_face - lo_face - (1 - c * ft * dt_2dx) * a6);
 }
 
+// physics adaptors used by the fused kernels (mfp_fused.hip, mfp_gather.hip); the staged
+// kernels use the same device functions through HydroPhys / FieldPhys
+template <int RECON_, int FLUX_> struct HydroF : HydroPhys<RECON_, FLUX_> {
+    typedef HydroParams Params;
+    static CMFP_DEV double gamma_of(const Params& P) { return P.gas.gamma; }
+    // prim -> cons, += k * dF, cons -> prim  (MFP_eulerian.cpp:1132-1176)
+    static CMFP_DEV bool correct(const Params& P, double* Q, double k, const double* dF) {
+        double U[5];
+        hydro_prim2cons(P.gas, Q, U);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) U[n] += k * dF[n];
+        return hydro_cons2prim(P.gas, U, Q);
+    }
+};
+template <int RECON_> struct FieldF : FieldPhys<RECON_> {
+    typedef FieldParams Params;
+    static CMFP_DEV double gamma_of(const Params&) { return 0.0; }
+    static CMFP_DEV bool correct(const Params&, double* Q, double k, const double* dF) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) Q[n] += k * dF[n];
+        return true;
+    }
+};
+
 }  // namespace CMFP_NS

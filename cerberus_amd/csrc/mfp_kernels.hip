@@ -525,6 +525,14 @@ CMFP_DEV double cell_plasma_dt(double Larmor, double Debye, double Bx, double By
 // the block partials of the CFL quantities of the values it just wrote
 // (max a+|u_d| per species, min plasma/cyclotron dt), so the dt estimate of the
 // next step costs no extra pass over the state.
+// plane-relative access: uniform base pointer (scalar registers) + 32-bit per-lane byte offset
+__device__ __forceinline__ double ld_plane(const double* base, unsigned off) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off);
+}
+__device__ __forceinline__ void st_plane(double* base, unsigned off, double v) {
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off) = v;
+}
+
 template <int NS, bool IMPL, bool REDUCE>
 __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs a, SourceCoef kf, double dt) {
     const long npts = box.npts();
@@ -532,17 +540,35 @@ __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs 
     double red_dt = DBL_MAX;
 #pragma unroll
     for (int s = 0; s < NS; ++s) red_speed[s] = DBL_MIN;
-    for (long t = (long)blockIdx.x * TPB + threadIdx.x; t < npts; t += (long)gridDim.x * TPB) {
-        int i, j, k;
-        decode(box, t, i, j, k);
-        const long c = g.at(i, j, k);
+    // grid-stride walk with the (i, j, k) index advanced incrementally: the 64-bit divisions of a
+    // per-cell decode cost more VALU work than the source terms themselves
+    const int l0 = box.hi[0] - box.lo[0] + 1, l1 = box.hi[1] - box.lo[1] + 1;
+    const long stride = (long)gridDim.x * TPB;
+    const int st0 = (int)(stride % l0), st1 = (int)((stride / l0) % l1), st2 = (int)(stride / l0 / l1);
+    long t = (long)blockIdx.x * TPB + threadIdx.x;
+    int ii = (int)(t % l0), jj = (int)((t / l0) % l1), kk = (int)(t / l0 / l1);
+    for (; t < npts; t += stride) {
+        // byte offset inside one component plane, 32-bit (cmfp_create bounds the plane at 4 GiB): with the
+        // uniform plane base in scalar registers every access is base + offset, no 64-bit address per comp
+        const unsigned c = (unsigned)g.at(box.lo[0] + ii, box.lo[1] + jj, box.lo[2] + kk) * 8u;
+        ii += st0;
+        if (ii >= l0) {
+            ii -= l0;
+            ++jj;
+        }
+        jj += st1;
+        if (jj >= l1) {
+            jj -= l1;
+            ++kk;
+        }
+        kk += st2;
         double f0[10], s0[NS][5], f1[10], s1[NS][5], sdU[NS][4], fdU[5];
 #pragma unroll
-        for (int n = 0; n < 10; ++n) f0[n] = a.f_U[c + n * g.sc];
+        for (int n = 0; n < 10; ++n) f0[n] = ld_plane(a.f_U + n * g.sc, c);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int n = 0; n < 5; ++n) s0[s][n] = a.sp_U[s][c + n * g.sc];
+            for (int n = 0; n < 5; ++n) s0[s][n] = ld_plane(a.sp_U[s] + n * g.sc, c);
         // stage 1
         if (IMPL)
             plasma5_implicit_cell<NS>(a, kf, dt, f0, s0, sdU, fdU);
@@ -576,7 +602,7 @@ __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs 
             for (int n = 0; n < 4; ++n) {
                 const double U2 = s1[s][n + 1] + sdU[s][n];
                 Un[n + 1] = 0.5 * s0[s][n + 1] + 0.5 * U2;
-                a.sp_U[s][c + (n + 1) * g.sc] = Un[n + 1];
+                st_plane(a.sp_U[s] + (n + 1) * g.sc, c, Un[n + 1]);
             }
             if (REDUCE) {
                 GasP G{1.0, 0.0, a.gamma[s]};
@@ -585,11 +611,11 @@ __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs 
             }
         }
         if (!a.lorentz_only) {
-            a.f_U[c + F_DX * g.sc] = 0.5 * f0[F_DX] + 0.5 * (f1[F_DX] + fdU[0]);
-            a.f_U[c + F_DY * g.sc] = 0.5 * f0[F_DY] + 0.5 * (f1[F_DY] + fdU[1]);
-            a.f_U[c + F_DZ * g.sc] = 0.5 * f0[F_DZ] + 0.5 * (f1[F_DZ] + fdU[2]);
-            a.f_U[c + F_PHI * g.sc] = 0.5 * f0[F_PHI] + 0.5 * (f1[F_PHI] + fdU[3]);
-            a.f_U[c + F_PSI * g.sc] = 0.5 * f0[F_PSI] + 0.5 * (f1[F_PSI] + fdU[4]);
+            st_plane(a.f_U + F_DX * g.sc, c, 0.5 * f0[F_DX] + 0.5 * (f1[F_DX] + fdU[0]));
+            st_plane(a.f_U + F_DY * g.sc, c, 0.5 * f0[F_DY] + 0.5 * (f1[F_DY] + fdU[1]));
+            st_plane(a.f_U + F_DZ * g.sc, c, 0.5 * f0[F_DZ] + 0.5 * (f1[F_DZ] + fdU[2]));
+            st_plane(a.f_U + F_PHI * g.sc, c, 0.5 * f0[F_PHI] + 0.5 * (f1[F_PHI] + fdU[3]));
+            st_plane(a.f_U + F_PSI * g.sc, c, 0.5 * f0[F_PSI] + 0.5 * (f1[F_PSI] + fdU[4]));
         }
     }
     if (REDUCE) {
@@ -979,6 +1005,17 @@ static int l_leaf_prim2cons(long n, double mass, double gamma, const double* Q, 
 // defined in mfp_fused.hip
 int ctu_fused(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
               const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
+#define CMFP_GATHER_DECL(D)                                                                                          \
+    int ctu_gather_##D(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2, \
+                       int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
+CMFP_GATHER_DECL(1) CMFP_GATHER_DECL(2) CMFP_GATHER_DECL(3)
+#undef CMFP_GATHER_DECL
+static int l_ctu_gather(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
+                        int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
+    if (g.dim == 1) return ctu_gather_1(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);
+    if (g.dim == 2) return ctu_gather_2(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);
+    return ctu_gather_3(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);
+}
 static void l_reduce_final(const double* part, int n, int is_max, unsigned long long* out, hipStream_t st) {
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, part, n, is_max, out);
 }
@@ -987,7 +1024,7 @@ const Launchers* launchers() {
     static const Launchers L = {l_prim,      l_recon,         l_face_bc,        l_fluxes,          l_correct,
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_fill_dim,        l_pack,
-                                ctu_fused,   l_source_fused,  l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
+                                ctu_fused,   l_source_fused,  l_ctu_gather, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
                                 l_leaf_prim2cons, l_reduce_final};
     return &L;
 }

@@ -117,6 +117,9 @@ struct Launchers {
     int (*ctu_fused)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
                      const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
     int (*source_fused)(const Geo&, const SourceArgs&, double dt, int reduce, hipStream_t);
+    // tile-free fused CTU update for any dimensionality (mfp_gather.hip); F1 / F2: face-flux scratch, 8 planes per direction
+    int (*ctu_gather)(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
+                      int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
     // batched leaves
     int (*leaf_reconstruct)(int recon, long n, const double* st, double* slope, double* lo, double* hi, hipStream_t);
     int (*leaf_riemann)(int flux, long n, const double* L, const double* R, double* F, double c0, double ch,

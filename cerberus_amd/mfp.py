@@ -162,6 +162,10 @@ class MFP:
     def last_advance_fused(self):
         return bool(self.L.cmfp_last_advance_fused(self.h))
 
+    def last_advance_path(self):
+        """0: staged kernels, 1: tiled fused kernels, 2: gather kernels (1-D / 3-D, or forced with fused=2)."""
+        return int(self.L.cmfp_last_advance_fused(self.h))
+
     def profile_enable(self, on=True):
         self._chk(self.L.cmfp_profile_enable(self.h, int(on)))
 

@@ -207,13 +207,15 @@ int cmfp_update_download(cmfp_context* ctx, int state, int which /*0=U,1=dU*/, d
 int cmfp_est_time_step(cmfp_context* ctx, double* dt);
 double cmfp_compute_new_dt(double est_dt, double old_dt);
 int cmfp_advance(cmfp_context* ctx, double time, double dt);
-/* Uses hand-fused kernels inside cmfp_advance where available (default 1);
- * 0 forces the stage-by-stage kernels that mirror the reference's FAB-level
- * functions one to one.  Results are identical. */
+/* Uses hand-fused kernels inside cmfp_advance where available (default 1: the
+ * LDS-tiled kernel for 2-D blocks, the tile-free gather kernels for 1-D and 3-D);
+ * 2 forces the gather kernels in any dimensionality; 0 forces the stage-by-stage
+ * kernels that mirror the reference's FAB-level functions one to one.  Results
+ * are identical. */
 int cmfp_set_fused(cmfp_context* ctx, int enable);
 
-/* 1 if the last cmfp_advance ran through the hand-fused kernels, 0 if it took
- * the stage-by-stage kernels. */
+/* Path the last cmfp_advance took: 0 stage-by-stage kernels, 1 tiled fused
+ * kernels, 2 gather kernels (for at least one state). */
 int cmfp_last_advance_fused(const cmfp_context* ctx);
 
 /* Per-kernel device timing: HIP events recorded on the context's stream around

@@ -110,9 +110,11 @@ def test_hydro_option_matrix(oracle, recon, flux):
     P = config.Problem(_kh(recon, flux), fp_mode=abi.FP_STRICT)
     ref = oracle.OracleSim(P)
     ref.run(5)
-    for fused in (False, True):
+    for fused in (False, True, 2):
         m = _gpu(P, fused=fused)
         m.run(5)
+        tiled = recon in ("minmod", "vanLeer", "MC", "centre")   # the rest: gather kernels only
+        assert m.last_advance_path() == (int(fused) if tiled or not fused else 2)
         assert np.array_equal(m.download(0), ref.get_state(0)), (recon, flux, fused)
         m.close()
 
@@ -154,7 +156,12 @@ def test_fused_path_is_taken_for_2d_strang():
     name, cfg, _ = small_cases()[0]
     m = _gpu(config.Problem(cfg))
     m.run(1)
-    assert not m.last_advance_fused()      # 1-D takes the staged kernels
+    assert m.last_advance_path() == 2      # 1-D and 3-D take the gather kernels
+    m.close()
+    name, cfg, _ = small_cases()[4]
+    m = _gpu(config.Problem(cfg))
+    m.run(1)
+    assert m.last_advance_path() == 2
     m.close()
 
 
@@ -180,12 +187,13 @@ def test_ragged_sizes(oracle):
         P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
         ref = oracle.OracleSim(P)
         ref.run(3)
-        m = _gpu(P)
-        m.run(3)
-        assert m.last_advance_fused()
-        for s in range(3):
-            assert np.array_equal(m.download(s), ref.get_state(s)), (n, s)
-        m.close()
+        for fused in (True, 2):
+            m = _gpu(P, fused=fused)
+            m.run(3)
+            assert m.last_advance_path() == int(fused)
+            for s in range(3):
+                assert np.array_equal(m.download(s), ref.get_state(s)), (n, s, fused)
+            m.close()
 
 
 def test_full_size_properties():

@@ -18,7 +18,7 @@ def _gpu(problem, **kw):
     return m
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, 2])   # staged / fused (tiled in 2-D, gather else) / gather
 @pytest.mark.parametrize("case", range(5))
 def test_nstep_parity_strict(oracle, case, fused):
     name, cfg, steps = small_cases()[case]
@@ -34,7 +34,7 @@ def test_nstep_parity_strict(oracle, case, fused):
     m.close()
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, 2])   # staged / fused (tiled in 2-D, gather else) / gather
 @pytest.mark.parametrize("case", range(5))
 def test_nstep_parity_fast(oracle, case, fused):
     name, cfg, steps = small_cases()[case]
