@@ -74,6 +74,7 @@ struct cmfp_context {
     int split[3];        // domain is split between ranks along d
     cmfp_exchange_fn exchange = nullptr;
     void* exchange_user = nullptr;
+    int exchange_batched = 0;  // one callback per dimension for all states (state = CMFP_ALL_STATES)
     int* d_err = nullptr;
     unsigned long long* d_red = nullptr;  // one reduction word per state + per action
     double* d_part = nullptr;             // CMFP_RED_BLOCKS block partials per word
@@ -193,6 +194,35 @@ int fill_patch(cmfp_context* c, int si) {
                 return fail(c, CMFP_ERR_INVALID, "domain is split along a dimension but no exchange callback is set");
             int r = c->exchange(c->exchange_user, c, si, d);
             if (r) return fail(c, CMFP_ERR_INVALID, "exchange callback failed");
+        }
+    }
+    return CMFP_OK;
+}
+
+// The same fill for several states at once, dimension by dimension: the states are independent, so
+// this equals fill_patch per state; with a batched exchange callback one message per neighbour and
+// dimension carries the ghost layers of every state.
+int fill_patch_many(cmfp_context* c, const std::vector<int>& list) {
+    const Geo& g = c->g;
+    ProfScope prof(c, CMFP_PROF_FILL);
+    for (int d = 0; d < g.dim; ++d) {
+        for (int si : list) {
+            StateRT& s = c->states[si];
+            for (int side = 0; side < 2; ++side) {
+                if (!c->split[d])
+                    c->L->fill_dim(g, s.sp.nc, s.sp.ng, s.new_data, d, side,
+                                   c->geom.is_periodic[d] ? wrap_rules(s) : bc_rules(s, d, side), c->stream);
+                else if (c->touches[d][side])
+                    c->L->fill_dim(g, s.sp.nc, s.sp.ng, s.new_data, d, side, bc_rules(s, d, side), c->stream);
+            }
+        }
+        if (!c->split[d]) continue;
+        if (!c->exchange) return fail(c, CMFP_ERR_INVALID, "domain is split along a dimension but no exchange callback is set");
+        if (c->exchange_batched) {
+            if (c->exchange(c->exchange_user, c, CMFP_ALL_STATES, d)) return fail(c, CMFP_ERR_INVALID, "exchange callback failed");
+        } else {
+            for (int si : list)
+                if (c->exchange(c->exchange_user, c, si, d)) return fail(c, CMFP_ERR_INVALID, "exchange callback failed");
         }
     }
     return CMFP_OK;
@@ -474,13 +504,22 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         ProfScope prof(c, CMFP_PROF_SOURCE);
         if (!c->L->source_fused(c->g, a, 0.5 * dt, 0, c->stream)) return 0;
     }
+    {
+        // ghost cells of every state a CTU action updates (stage B FillPatch, MFP_advance.cpp:209);
+        // the flux kernels below write the ping-pong partners, so all fills can go first
+        std::vector<int> list;
+        for (const auto& A : c->actions)
+            if (A.kind == CMFP_ACTION_CTU)
+                for (int i = 0; i < A.n_states; ++i) list.push_back(A.states[i]);
+        int r;
+        if ((r = fill_patch_many(c, list))) return r;
+    }
     for (const auto& A : c->actions) {
         if (A.kind != CMFP_ACTION_CTU) continue;
         for (int i = 0; i < A.n_states; ++i) {
             StateRT& s = c->states[A.states[i]];
             int r;
             if ((r = dalloc(c, &s.alt, s.sp.nc * c->g.sc))) return r;
-            if ((r = fill_patch(c, A.states[i]))) return r;
             // a hydro state no source action touches afterwards: the CTU kernel is the last writer of
             // the step and also leaves the CFL reduction of what it wrote
             bool reduce = s.sp.kind == CMFP_STATE_HYDRO;
@@ -933,6 +972,12 @@ int cmfp_set_exchange_callback(cmfp_context* c, cmfp_exchange_fn fn, void* user)
     c->exchange_user = user;
     return CMFP_OK;
 }
+int cmfp_set_exchange_batched(cmfp_context* c, int on) {
+    if (!c) return CMFP_ERR_INVALID;
+    c->exchange_batched = on != 0;
+    return CMFP_OK;
+}
+
 int cmfp_fill_patch(cmfp_context* c, int s) {
     int r;
     if ((r = check_ctx(c))) return r;

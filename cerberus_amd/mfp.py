@@ -40,7 +40,8 @@ def coords_rank(c, grid):
 
 
 class MFP:
-    def __init__(self, problem, device=0, rank=0, world=1, stream=0, fused=True, pg=None, exchange_device=None):
+    def __init__(self, problem, device=0, rank=0, world=1, stream=0, fused=True, pg=None, exchange_device=None,
+                 batched_exchange=True):
         self.L = lib.load()
         self.p = problem if isinstance(problem, Problem) else Problem(problem)
         p = self.p
@@ -75,6 +76,7 @@ class MFP:
         if world > 1:
             self._cb = lib.EXCHANGE_FN(self._exchange)
             self._chk(self.L.cmfp_set_exchange_callback(self.h, self._cb, None))
+            self._chk(self.L.cmfp_set_exchange_batched(self.h, int(batched_exchange)))
 
     # ------------------------------------------------------------------
     def _chk(self, rc):
@@ -219,11 +221,10 @@ class MFP:
     def _halo_unpack(self, s, d, side, buf):
         self._chk(self.L.cmfp_halo_unpack(self.h, s, d, side, C.c_void_p(buf.data_ptr())))
 
-    def _buffers(self, s, d):
+    def _buffers(self, s, d, n):
         import torch
         key = (s, d)
         if key not in self._bufs:
-            n = self._halo_count(s, d)
             dev = self._pack_device()
             dbuf = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(4)]
             if self._exchange_device is not None and torch.device(self._exchange_device) != dev:
@@ -240,16 +241,21 @@ class MFP:
 
     def _exchange(self, user, ctx, s, d):
         """cmfp_exchange_fn: pack both faces, swap with the neighbours, unpack.
-        Buffers 0/1 = send lo/hi, 2/3 = recv lo/hi."""
+        Buffers 0/1 = send lo/hi, 2/3 = recv lo/hi.  s = CMFP_ALL_STATES (-1): the
+        faces of every state travel back to back in one message per neighbour."""
         try:
             import torch.distributed as dist
-            dbuf, xbuf = self._buffers(s, d)
+            states = list(range(self.n_states)) if s < 0 else [s]
+            counts = [self._halo_count(q, d) for q in states]
+            offs = [sum(counts[:k]) for k in range(len(counts))]
+            dbuf, xbuf = self._buffers(s, d, sum(counts))
             staged = xbuf is not dbuf
             nb_lo, nb_hi = self.neighbour(d, 0), self.neighbour(d, 1)
-            if nb_lo is not None:
-                self._halo_pack(s, d, 0, dbuf[0])
-            if nb_hi is not None:
-                self._halo_pack(s, d, 1, dbuf[1])
+            for q, off, n in zip(states, offs, counts):
+                if nb_lo is not None:
+                    self._halo_pack(q, d, 0, dbuf[0][off:off + n])
+                if nb_hi is not None:
+                    self._halo_pack(q, d, 1, dbuf[1][off:off + n])
             if staged:
                 for k in (0, 1):
                     xbuf[k].copy_(dbuf[k])
@@ -274,10 +280,11 @@ class MFP:
             if staged:
                 for k in (2, 3):
                     dbuf[k].copy_(xbuf[k])
-            if nb_lo is not None:
-                self._halo_unpack(s, d, 0, dbuf[2])
-            if nb_hi is not None:
-                self._halo_unpack(s, d, 1, dbuf[3])
+            for q, off, n in zip(states, offs, counts):
+                if nb_lo is not None:
+                    self._halo_unpack(q, d, 0, dbuf[2][off:off + n])
+                if nb_hi is not None:
+                    self._halo_unpack(q, d, 1, dbuf[3][off:off + n])
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             import traceback

@@ -245,6 +245,13 @@ int cmfp_profile_read(cmfp_context* ctx, int slot, long long* launches, double* 
  * library. */
 typedef int (*cmfp_exchange_fn)(void* user, cmfp_context* ctx, int state, int dim);
 int cmfp_set_exchange_callback(cmfp_context* ctx, cmfp_exchange_fn fn, void* user);
+/* Batched exchanges (default off): inside cmfp_advance the fused Strang step fills the ghost cells
+ * of all states together and, with this set, calls the callback once per split dimension with
+ * state = CMFP_ALL_STATES; the callback then packs every state of the context into one message
+ * per neighbour (one exchange per dimension and step instead of one per state: the reference's
+ * FillPatch is per state, MFP_action.cpp:59; the data moved is the same). */
+#define CMFP_ALL_STATES (-1)
+int cmfp_set_exchange_batched(cmfp_context* ctx, int on);
 int cmfp_fill_patch(cmfp_context* ctx, int state);
 /* Number of doubles in one packed face of `state` normal to `dim`. */
 long long cmfp_halo_count(const cmfp_context* ctx, int state, int dim);

@@ -15,7 +15,8 @@ import torch.multiprocessing as mp
 from cerberus_amd import config, problems
 from cerberus_amd.mfp import MFP, block_grid, rank_coords
 
-NG, NC = 2, 3
+NG = 2
+NCS = [3, 2]   # two states with different component counts (batched mode packs them back to back)
 
 
 class HostHaloMFP(MFP):
@@ -32,14 +33,16 @@ class HostHaloMFP(MFP):
         self._exchange_device = "cpu"
         self.p.periodic = periodic
         ny, nx = self.block_n[1], self.block_n[0]
-        self.A = np.full((NC, ny + 2 * NG, nx + 2 * NG), np.nan)
+        self.n_states = len(NCS)
+        self.As = [np.full((nc, ny + 2 * NG, nx + 2 * NG), np.nan) for nc in NCS]
 
     def _pack_device(self):
         return torch.device("cpu")
 
     def _halo_count(self, s, d):
-        other = self.A.shape[1] if d == 0 else self.A.shape[2]
-        return NC * NG * other
+        A = self.As[s]
+        other = A.shape[1] if d == 0 else A.shape[2]
+        return A.shape[0] * NG * other
 
     def _slab(self, d, first):
         # NG layers starting at local index `first` (ghost-inclusive offset NG), full extent otherwise
@@ -50,25 +53,26 @@ class HostHaloMFP(MFP):
     def _halo_pack(self, s, d, side, buf):
         n = self.block_n[d]
         first = 0 if side == 0 else n - NG
-        buf.copy_(torch.from_numpy(np.ascontiguousarray(self.A[self._slab(d, first)]).ravel()))
+        buf.copy_(torch.from_numpy(np.ascontiguousarray(self.As[s][self._slab(d, first)]).ravel()))
 
     def _halo_unpack(self, s, d, side, buf):
         n = self.block_n[d]
         first = -NG if side == 0 else n
         sl = self._slab(d, first)
-        self.A[sl] = buf.numpy().reshape(self.A[sl].shape)
+        self.As[s][sl] = buf.numpy().reshape(self.As[s][sl].shape)
 
     def local_wrap(self, d):
         n = self.block_n[d]
-        if d == 0:
-            self.A[:, :, :NG] = self.A[:, :, n:n + NG]
-            self.A[:, :, n + NG:] = self.A[:, :, NG:2 * NG]
-        else:
-            self.A[:, :NG, :] = self.A[:, n:n + NG, :]
-            self.A[:, n + NG:, :] = self.A[:, NG:2 * NG, :]
+        for A in self.As:
+            if d == 0:
+                A[:, :, :NG] = A[:, :, n:n + NG]
+                A[:, :, n + NG:] = A[:, :, NG:2 * NG]
+            else:
+                A[:, :NG, :] = A[:, n:n + NG, :]
+                A[:, n + NG:, :] = A[:, NG:2 * NG, :]
 
 
-def _worker(rank, world, port, n, periodic, ret):
+def _worker(rank, world, port, n, periodic, batched, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -76,31 +80,37 @@ def _worker(rank, world, port, n, periodic, ret):
         P = config.Problem(problems.kelvin_helmholtz_2d(n))
         m = HostHaloMFP(P, rank, world, periodic)
         rng = np.random.default_rng(7)
-        G = rng.standard_normal((NC, n, n))                       # the global field, same on every rank
+        Gs = [rng.standard_normal((nc, n, n)) for nc in NCS]      # the global fields, same on every rank
         j0, i0 = m.block_lo[1], m.block_lo[0]
         ny, nx = m.block_n[1], m.block_n[0]
-        m.A[:, NG:-NG, NG:-NG] = G[:, j0:j0 + ny, i0:i0 + nx]
-        for d in range(2):                                        # the fill_patch loop of the library
+        for A, G in zip(m.As, Gs):
+            A[:, NG:-NG, NG:-NG] = G[:, j0:j0 + ny, i0:i0 + nx]
+        for d in range(2):                                        # the fill_patch_many loop of the library
             if m.grid[d] == 1:
                 if periodic[d]:
                     m.local_wrap(d)
+            elif batched:
+                assert m._exchange(None, None, -1, d) == 0        # CMFP_ALL_STATES
             else:
-                assert m._exchange(None, None, 0, d) == 0
+                for s in range(m.n_states):
+                    assert m._exchange(None, None, s, d) == 0
         # expected: periodic pad of the global field (ghosts at physical faces stay NaN)
-        pad = np.pad(G, ((0, 0), (NG, NG), (NG, NG)), mode="wrap")
-        exp = pad[:, j0:j0 + ny + 2 * NG, i0:i0 + nx + 2 * NG].copy()
-        for d in range(2):
-            if not periodic[d]:
-                ax = 2 - d
-                if m.coords[d] == 0:
-                    sl = [slice(None)] * 3
-                    sl[ax] = slice(0, NG)
-                    exp[tuple(sl)] = np.nan
-                if m.coords[d] == m.grid[d] - 1:
-                    sl = [slice(None)] * 3
-                    sl[ax] = slice(-NG, None)
-                    exp[tuple(sl)] = np.nan
-        ok = np.array_equal(m.A, exp, equal_nan=True)
+        ok = True
+        for A, G in zip(m.As, Gs):
+            pad = np.pad(G, ((0, 0), (NG, NG), (NG, NG)), mode="wrap")
+            exp = pad[:, j0:j0 + ny + 2 * NG, i0:i0 + nx + 2 * NG].copy()
+            for d in range(2):
+                if not periodic[d]:
+                    ax = 2 - d
+                    if m.coords[d] == 0:
+                        sl = [slice(None)] * 3
+                        sl[ax] = slice(0, NG)
+                        exp[tuple(sl)] = np.nan
+                    if m.coords[d] == m.grid[d] - 1:
+                        sl = [slice(None)] * 3
+                        sl[ax] = slice(-NG, None)
+                        exp[tuple(sl)] = np.nan
+            ok = ok and np.array_equal(A, exp, equal_nan=True)
         # dt min-reduction path
         m._exchange_device = "cpu"
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
@@ -118,12 +128,13 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("world,periodic", [(2, [1, 1, 0]), (4, [1, 1, 0]), (2, [1, 0, 0]), (4, [0, 1, 0])])
-def test_halo_exchange_protocol(world, periodic):
+def test_halo_exchange_protocol(world, periodic, batched):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 16, periodic, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 16, periodic, batched, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, which, ret):
+def _worker(rank, world, port, which, batched, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -25,9 +25,8 @@ def _worker(rank, world, port, which, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        cfg = problems.orszag_tang_two_fluid_2d(32) if which == "ot" else problems.gem_reconnection_2d(32, 32)
-        P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
-        m = MFP(P, device=0, rank=rank, world=world, exchange_device="cpu")
+        P = config.Problem(_cfg(which), fp_mode=abi.FP_STRICT)
+        m = MFP(P, device=0, rank=rank, world=world, exchange_device="cpu", batched_exchange=batched)
         m.init_data()
         dts = m.run(5)
         out = {"dts": dts, "lo": m.block_lo, "n": m.block_n, "fused": m.last_advance_fused(),
@@ -38,6 +37,15 @@ def _worker(rank, world, port, which, ret):
         dist.destroy_process_group()
 
 
+def _cfg(which):
+    from cerberus_amd import problems
+    if which == "ot":
+        return problems.orszag_tang_two_fluid_2d(32)
+    if which == "gem":
+        return problems.gem_reconnection_2d(32, 32)
+    return problems.richtmyer_meshkov_3d(16, 16, 16)     # 3-D: gather kernels, 1x2x2 blocks
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -46,22 +54,22 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,which", [(2, "ot"), (4, "ot"), (4, "gem")])
-def test_decomposed_run_equals_single_rank(world, which):
+@pytest.mark.parametrize("world,which,batched", [(2, "ot", True), (4, "ot", True), (4, "ot", False), (4, "gem", True),
+                                                 (4, "rmi3d", True)])
+def test_decomposed_run_equals_single_rank(world, which, batched):
     import torch.multiprocessing as mp
     from cerberus_amd import abi, config, problems
     from cerberus_amd.mfp import MFP
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, which, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, which, batched, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(240)
         assert p.exitcode == 0
-    cfg = problems.orszag_tang_two_fluid_2d(32) if which == "ot" else problems.gem_reconnection_2d(32, 32)
-    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    P = config.Problem(_cfg(which), fp_mode=abi.FP_STRICT)
     m = MFP(P, device=0)
     m.init_data()
     dts = m.run(5)
@@ -73,5 +81,5 @@ def test_decomposed_run_equals_single_rank(world, which):
         assert o["fused"]
         lo, n = o["lo"], o["n"]
         for s in range(len(full)):
-            ref = full[s][:, :, lo[1]:lo[1] + n[1], lo[0]:lo[0] + n[0]]
+            ref = full[s][:, lo[2]:lo[2] + n[2], lo[1]:lo[1] + n[1], lo[0]:lo[0] + n[0]]
             assert np.array_equal(o["data"][s], ref), (r, s)
