@@ -34,13 +34,26 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(k)
 #endif
 
+// value of the lane one to the left / right inside a row of 16 lanes (= the x-neighbour thread for
+// BX = 16): DPP row shifts, register to register, no LDS.  Every lane of the wave must execute these.
+CMFP_DEV double from_left(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, false);  // row_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+CMFP_DEV double from_right(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x101, 0xf, 0xf, false);  // row_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x101, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 struct FaceBC {
     int touch[2][2];   // [d][side]: physical (non-periodic) domain face on this block
     int rule[2][2][10];  // FILL_SKIP / FILL_EVEN / FILL_ODD per primitive comp
 };
 
 template <class Phys, int BX, int BY, bool HAS_BC, bool REDUCE>
-__global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
+__global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
                                                    double* __restrict__ Uout, int do_ctu, double dt, FaceBC bc, int* err,
                                                    int gx, int nblk, unsigned long long* red) {
     constexpr int NQ = Phys::NQ, NC = Phys::NC, NF = Phys::NF, RECON = Phys::RECON;
@@ -48,9 +61,13 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
     constexpr int TX = BX - 2, TY = BY - 2;
     constexpr int PX = BX + 2 * H, PY = BY + 2 * H;
     constexpr int C = BX * BY;
-    constexpr int NA = (NQ * PX * PY > 2 * NF * C) ? NQ * PX * PY : 2 * NF * C;
-    __shared__ double bufA[NA];          // phase 0-1: primitives; phase 2-5: face fluxes
-    __shared__ double bufR[2 * NQ * C];  // high-side face states of every cell, both directions
+    static_assert(BX == 16, "the x-neighbour exchange uses DPP shifts inside rows of 16 lanes");
+    // primitives go through LDS NH components at a time: all of them for hydro (cons2prim couples
+    // them), two halves for the field, whose 22 x 22 x 10 tile alone would cap the CU at 2 workgroups
+    constexpr int NH = Phys::IS_HYDRO ? NQ : (NQ + 1) / 2;
+    constexpr int NA = (NH * PX * PY > NF * C) ? NH * PX * PY : NF * C;
+    __shared__ double bufA[NA];      // phase 0-1: primitives; phase 2-5: y-face fluxes
+    __shared__ double bufR[NQ * C];  // high-side y-face states of every cell (x-neighbours talk by DPP)
     double* const Pq = bufA;
     double* const Fb = bufA;
 
@@ -70,56 +87,77 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
     unsigned long long t_prev_ = __builtin_readcyclecounter();
 #endif
 
-    // ---- phase 0: conserved -> primitives for the tile grown by 1 + H
-    for (int t = tid; t < PX * PY; t += C) {
-        const int px = t % PX, py = t / PX;
-        const int ci = i0 - 1 - H + px, cj = j0 - 1 - H + py;
-        if (ci >= -(1 + H) && ci <= n0 + H && cj >= -(1 + H) && cj <= n1 + H) {
-            const long c = g.at(ci, cj, 0);
-            double U[NC], Q[NQ];
-#pragma unroll
-            for (int n = 0; n < NC; ++n) U[n] = Uin[c + n * g.sc];
-            if (!Phys::cons2prim(P, U, Q)) *err = 1;
-            if (Phys::IS_HYDRO) Q[H_P] = f_div(Q[H_P], gm1);  // eps = p / (gamma - 1), MFP_hydro.cpp:847-862
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) Pq[n * (PX * PY) + t] = Q[n];
-        }
-    }
-    STAMP(0);
-    __syncthreads();
-    STAMP(1);
-
-    // ---- phase 1: reconstruction + half-step trace of this cell, both directions
+    // ---- phases 0 + 1, NH components at a time:
+    //   0: conserved -> primitives for the tile grown by 1 + H, into LDS
+    //   1: reconstruction + half-step trace of this cell, both directions
     double lo[2][NQ], hi[2][NQ];
-    {
-        const int pc = (ty + H) * PX + (tx + H);
-        double centre[NQ], speed[3];
-        unsigned flat = 0;  // FAST mode, field: (direction, component) pairs whose stencil is flat
+    double speed[3];
+    unsigned flat = 0;  // FAST mode, field: (direction, component) pairs whose stencil is flat
+    const int pc = (ty + H) * PX + (tx + H);
 #pragma unroll
-        for (int n = 0; n < NQ; ++n) centre[n] = Pq[n * (PX * PY) + pc];
-        if (Phys::IS_HYDRO) centre[H_P] = centre[H_P] * gm1;  // restored pressure, MFP_hydro.cpp:1025-1035
-        Phys::speed_from_prim(P, centre, speed);
+    for (int h0 = 0; h0 < NQ; h0 += NH) {
+        for (int t = tid; t < PX * PY; t += C) {
+            const int px = t % PX, py = t / PX;
+            const int ci = i0 - 1 - H + px, cj = j0 - 1 - H + py;
+            if (ci >= -(1 + H) && ci <= n0 + H && cj >= -(1 + H) && cj <= n1 + H) {
+                const long c = g.at(ci, cj, 0);
+                if constexpr (Phys::IS_HYDRO) {
+                    double U[NC], Q[NQ];
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const int sd = d == 0 ? 1 : PX;
-            if constexpr (Phys::IS_HYDRO) {
+                    for (int n = 0; n < NC; ++n) U[n] = Uin[c + n * g.sc];
+                    if (!Phys::cons2prim(P, U, Q)) *err = 1;
+                    Q[H_P] = f_div(Q[H_P], gm1);  // eps = p / (gamma - 1), MFP_hydro.cpp:847-862
+#pragma unroll
+                    for (int n = 0; n < NQ; ++n) Pq[n * (PX * PY) + t] = Q[n];
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NH; ++n)
+                        if (h0 + n < NQ) Pq[n * (PX * PY) + t] = Uin[c + (h0 + n) * g.sc];  // FieldState: prim = cons
+                }
+            }
+        }
+        STAMP(0);
+        __syncthreads();
+        STAMP(1);
+        if constexpr (Phys::IS_HYDRO) {
+            double centre[NQ];
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) centre[n] = Pq[n * (PX * PY) + pc];
+            centre[H_P] = centre[H_P] * gm1;  // restored pressure, MFP_hydro.cpp:1025-1035
+            Phys::speed_from_prim(P, centre, speed);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int sd = d == 0 ? 1 : PX;
                 double st[SL][5];
 #pragma unroll
                 for (int s = 0; s < SL; ++s)
 #pragma unroll
                     for (int n = 0; n < 5; ++n) st[s][n] = Pq[n * (PX * PY) + pc + (s - H) * sd];
                 hydro_cell_faces<RECON>(Phys::gamma_of(P), st, lo[d], hi[d]);
-            } else {
+                if (do_ctu) {
+                    const double dt_2dx = 0.5 * dt / g.dx[d];
 #pragma unroll
-                for (int n = 0; n < NQ; ++n) {
+                    for (int n = 0; n < NQ; ++n) trace_faces(speed[d], dt_2dx, centre[n], lo[d][n], hi[d][n]);
+                }
+            }
+        } else {
+            Phys::speed_from_prim(P, nullptr, speed);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int sd = d == 0 ? 1 : PX;
+                const double dt_2dx = 0.5 * dt / g.dx[d];
+#pragma unroll
+                for (int m = 0; m < NH; ++m) {
+                    const int n = h0 + m;
+                    if (n >= NQ) continue;
                     double st[SL];
 #pragma unroll
-                    for (int s = 0; s < SL; ++s) st[s] = Pq[n * (PX * PY) + pc + (s - H) * sd];
+                    for (int s = 0; s < SL; ++s) st[s] = Pq[m * (PX * PY) + pc + (s - H) * sd];
 #ifdef CMFP_FASTMATH
                     // FAST mode: the material coefficients mu, ep never change (F = 0, no source);
                     // where their stencil is flat the face values are the cell value itself (the
                     // weights sum to one; the STRICT evaluation gives 1 + 2^-52 for O6) and the
-                    // trace below is the identity, so the Riemann solver sees exact vacuum values.
+                    // trace is the identity, so the Riemann solver sees exact vacuum values.
                     if (n >= F_MU) {
                         bool same = true;
 #pragma unroll
@@ -132,43 +170,38 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
                     }
 #endif
                     recon_faces<RECON>(st, lo[d][n], hi[d][n]);
+                    if (do_ctu) trace_faces(speed[d], dt_2dx, st[H], lo[d][n], hi[d][n]);
                 }
             }
-            if (do_ctu) {
-                const double dt_2dx = 0.5 * dt / g.dx[d];
-#pragma unroll
-                for (int n = 0; n < NQ; ++n)
-                    if (!((flat >> (d * 16 + n)) & 1u)) trace_faces(speed[d], dt_2dx, centre[n], lo[d][n], hi[d][n]);
-            }
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) bufR[(d * NQ + n) * C + tid] = hi[d][n];
         }
+#pragma unroll
+        for (int m = 0; m < NH; ++m)
+            if (h0 + m < NQ) bufR[(h0 + m) * C + tid] = hi[1][h0 + m];
+        STAMP(2);
+        __syncthreads();
+        STAMP(3);
     }
-    STAMP(2);
-    __syncthreads();
-    STAMP(3);
+    (void)flat;
 
     // ---- phase 2: Riemann sweep 1 on the low faces of this cell
     double fx[NC] = {0}, fy[NC] = {0};
     {
         double L[NQ];
-        if (tx >= 1) {
 #pragma unroll
-            for (int n = 0; n < NQ; ++n) L[n] = bufR[(0 * NQ + n) * C + tid - 1];
-            Phys::riemann(P, 0, L, lo[0], fx);
-        }
+        for (int n = 0; n < NQ; ++n) L[n] = from_left(hi[0][n]);
+        if (tx >= 1) Phys::riemann(P, 0, L, lo[0], fx);
         if (ty >= 1) {
 #pragma unroll
-            for (int n = 0; n < NQ; ++n) L[n] = bufR[(1 * NQ + n) * C + tid - BX];
+            for (int n = 0; n < NQ; ++n) L[n] = bufR[n * C + tid - BX];
             Phys::riemann(P, 1, L, lo[1], fy);
         }
     }
     if (do_ctu) {
 #pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            Fb[(0 * NF + n) * C + tid] = fx[n];
-            Fb[(1 * NF + n) * C + tid] = fy[n];
-        }
+        for (int n = 0; n < NF; ++n) Fb[n * C + tid] = fy[n];
+        double fxr[NF];  // x-flux at the high x-face = the right neighbour's low face
+#pragma unroll
+        for (int n = 0; n < NF; ++n) fxr[n] = from_right(fx[n]);
         STAMP(4);
         __syncthreads();
         STAMP(5);
@@ -183,7 +216,7 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
             double dF[NF];
             const double k = 0.5 * dt / g.dx[1];
 #pragma unroll
-            for (int n = 0; n < NF; ++n) dF[n] = fy[n] - Fb[(1 * NF + n) * C + tid + BX];
+            for (int n = 0; n < NF; ++n) dF[n] = fy[n] - Fb[n * C + tid + BX];
             if (tx <= BX - 2 && i < n0) {
                 if (!Phys::correct(P, hi[0], k, dF)) *err = 1;
             }
@@ -195,7 +228,7 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
             double dF[NF];
             const double k = 0.5 * dt / g.dx[0];
 #pragma unroll
-            for (int n = 0; n < NF; ++n) dF[n] = fx[n] - Fb[(0 * NF + n) * C + tid + 1];
+            for (int n = 0; n < NF; ++n) dF[n] = fx[n] - fxr[n];
             if (ty <= BY - 2 && j < n1) {
                 if (!Phys::correct(P, hi[1], k, dF)) *err = 1;
             }
@@ -204,9 +237,7 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
             }
         }
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) bufR[(d * NQ + n) * C + tid] = hi[d][n];
+        for (int n = 0; n < NQ; ++n) bufR[n * C + tid] = hi[1][n];
         STAMP(6);
         __syncthreads();
         STAMP(7);
@@ -214,12 +245,11 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
         // ---- phase 4: domain-face BCs (update_face_prim, do_all) + Riemann sweep 2
         {
             double L[NQ], R[NQ];
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) L[n] = from_left(hi[0][n]);
             if (tx >= 1) {
 #pragma unroll
-                for (int n = 0; n < NQ; ++n) {
-                    L[n] = bufR[(0 * NQ + n) * C + tid - 1];
-                    R[n] = lo[0][n];
-                }
+                for (int n = 0; n < NQ; ++n) R[n] = lo[0][n];
                 if (HAS_BC && bc.touch[0][0] && i == 0) {
 #pragma unroll
                     for (int n = 0; n < NQ; ++n)
@@ -235,7 +265,7 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
             if (ty >= 1) {
 #pragma unroll
                 for (int n = 0; n < NQ; ++n) {
-                    L[n] = bufR[(1 * NQ + n) * C + tid - BX];
+                    L[n] = bufR[n * C + tid - BX];
                     R[n] = lo[1][n];
                 }
                 if (HAS_BC && bc.touch[1][0] && j == 0) {
@@ -253,10 +283,10 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
         }
     }
 #pragma unroll
-    for (int n = 0; n < NF; ++n) {
-        Fb[(0 * NF + n) * C + tid] = fx[n];
-        Fb[(1 * NF + n) * C + tid] = fy[n];
-    }
+    for (int n = 0; n < NF; ++n) Fb[n * C + tid] = fy[n];
+    double fxh[NF];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) fxh[n] = from_right(fx[n]);
     STAMP(8);
     __syncthreads();
     STAMP(9);
@@ -271,8 +301,8 @@ __global__ __launch_bounds__(BX* BY) void k_ctu2d(Geo g, typename Phys::Params P
         for (int n = 0; n < NC; ++n) {
             double du = 0.0;
             if (n < NF) {
-                du += dtdx * (fx[n] - Fb[(0 * NF + n) * C + tid + 1]);
-                du += dtdy * (fy[n] - Fb[(1 * NF + n) * C + tid + BX]);
+                du += dtdx * (fx[n] - fxh[n]);
+                du += dtdy * (fy[n] - Fb[n * C + tid + BX]);
             } else {
                 du += dtdx * (0.0 - 0.0);
                 du += dtdy * (0.0 - 0.0);
