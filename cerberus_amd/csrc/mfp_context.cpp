@@ -74,7 +74,10 @@ struct cmfp_context {
     int split[3];        // domain is split between ranks along d
     cmfp_exchange_fn exchange = nullptr;
     void* exchange_user = nullptr;
-    int exchange_batched = 0;  // one callback per dimension for all states (state = CMFP_ALL_STATES)
+    int exchange_batched = 0;
+    int overlap = 1;           // 1: interior flux tiles overlap the halo exchange where the block is split; 2: always split the launches
+    hipStream_t stream2 = nullptr;  // interior tiles run here while ghost cells are in flight on `stream`
+    hipEvent_t ev_src = nullptr, ev_int = nullptr;  // one callback per dimension for all states (state = CMFP_ALL_STATES)
     int* d_err = nullptr;
     unsigned long long* d_red = nullptr;  // one reduction word per state + per action
     double* d_part = nullptr;             // CMFP_RED_BLOCKS block partials per word
@@ -83,6 +86,7 @@ struct cmfp_context {
     int last_fused = 0;
     int profiling = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[CMFP_PROF_NSLOTS];
+    long prof_uncounted[CMFP_PROF_NSLOTS] = {0, 0, 0, 0};
     std::vector<hipEvent_t> ev_pool;
     std::vector<double*> allocs;
     std::vector<double> staging;
@@ -105,6 +109,8 @@ int fail(cmfp_context* c, int code, const std::string& msg) {
 struct ProfScope {
     cmfp_context* c;
     int slot;
+    hipStream_t st;
+    bool count;  // false: the time is added to the slot but not counted as a launch (second half of a split launch)
     hipEvent_t a = nullptr, b = nullptr;
     static hipEvent_t get(cmfp_context* c) {
         hipEvent_t e = nullptr;
@@ -116,16 +122,18 @@ struct ProfScope {
         }
         return e;
     }
-    ProfScope(cmfp_context* ctx, int s) : c(ctx), slot(s) {
+    ProfScope(cmfp_context* ctx, int s) : ProfScope(ctx, s, ctx->stream, true) {}
+    ProfScope(cmfp_context* ctx, int s, hipStream_t stream, bool cnt) : c(ctx), slot(s), st(stream), count(cnt) {
         if (!c->profiling) return;
         a = get(c);
         b = get(c);
-        if (a) (void)hipEventRecord(a, c->stream);
+        if (a) (void)hipEventRecord(a, st);
     }
     ~ProfScope() {
         if (!a || !b) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         c->prof[slot].push_back({a, b});
+        if (!count) c->prof_uncounted[slot]++;
     }
 };
 
@@ -484,7 +492,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             for (int i = 0; i < A.n_states; ++i) {
                 const StatePhys& sp = c->states[A.states[i]].sp;
                 if (c->fused != 2 && c->L->ctu_fused(c->g, sp, nullptr, nullptr, A.corner_transport, dt, c->touches, nullptr,
-                                                     nullptr, c->stream)) {
+                                                     nullptr, 0, c->stream)) {
                     tiled[A.states[i]] = 1;
                 } else if (c->L->ctu_gather(c->g, sp, nullptr, nullptr, none, none, A.corner_transport, dt, c->touches,
                                             nullptr, nullptr, c->stream)) {
@@ -504,51 +512,81 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         ProfScope prof(c, CMFP_PROF_SOURCE);
         if (!c->L->source_fused(c->g, a, 0.5 * dt, 0, c->stream)) return 0;
     }
+    std::vector<int> list;  // every state a CTU action updates, with its action's corner_transport flag
+    std::vector<int> ctu_flag;
+    for (const auto& A : c->actions)
+        if (A.kind == CMFP_ACTION_CTU)
+            for (int i = 0; i < A.n_states; ++i) {
+                list.push_back(A.states[i]);
+                ctu_flag.push_back(A.corner_transport);
+            }
+    // Halo/compute overlap: where the block is split between ranks, the flux update of the tiles
+    // whose stencils stay inside valid cells runs on a second stream while the ghost layers are
+    // packed, exchanged and unpacked on the main one; the frame of boundary tiles follows the fill.
+    bool split_any = false;
+    for (int d = 0; d < c->g.dim; ++d) split_any = split_any || c->split[d];
+    bool overlap = c->overlap == 2 || (c->overlap == 1 && split_any);
+    for (size_t q = 0; q < list.size() && overlap; ++q)
+        overlap = tiled[list[q]] && c->L->ctu_fused(c->g, c->states[list[q]].sp, nullptr, nullptr, ctu_flag[q], dt, c->touches,
+                                                    nullptr, nullptr, 1, c->stream);
+    if (overlap && !c->stream2) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming));
+    }
+    std::vector<unsigned long long*> slots(list.size(), nullptr);
+    for (size_t q = 0; q < list.size(); ++q) {
+        StateRT& s = c->states[list[q]];
+        int r;
+        if ((r = dalloc(c, &s.alt, s.sp.nc * c->g.sc))) return r;
+        // a hydro state no source action touches afterwards: the CTU kernel is the last writer of
+        // the step and also leaves the CFL reduction of what it wrote
+        bool reduce = s.sp.kind == CMFP_STATE_HYDRO;
+        if (src >= 0) {
+            const cmfp_action_desc& SA = c->actions[src];
+            for (int k = 0; k < SA.n_states - 1; ++k)
+                if (SA.states[k] == list[q]) reduce = false;
+        }
+        if (reduce) {
+            slots[q] = reinterpret_cast<unsigned long long*>(c->d_part + (size_t)list[q] * CMFP_RED_BLOCKS);
+            HIPCHK(c, hipMemsetAsync(slots[q], 0, 256 * sizeof(unsigned long long), c->stream));
+        }
+    }
+    const Ptr3 F1{{c->gF1[0], c->gF1[1], c->gF1[2]}}, F2{{c->gF2[0], c->gF2[1], c->gF2[2]}};
+    auto slot_of = [&](const StateRT& s) { return s.sp.kind == CMFP_STATE_HYDRO ? CMFP_PROF_CTU_HYDRO : CMFP_PROF_CTU_FIELD; };
+    if (overlap) {
+        HIPCHK(c, hipEventRecord(c->ev_src, c->stream));  // source stage A (and the slot resets) done
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_src, 0));
+        for (size_t q = 0; q < list.size(); ++q) {
+            StateRT& s = c->states[list[q]];
+            ProfScope prof(c, slot_of(s), c->stream2, true);
+            c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], 1, c->stream2);
+        }
+        HIPCHK(c, hipEventRecord(c->ev_int, c->stream2));
+    }
     {
-        // ghost cells of every state a CTU action updates (stage B FillPatch, MFP_advance.cpp:209);
-        // the flux kernels below write the ping-pong partners, so all fills can go first
-        std::vector<int> list;
-        for (const auto& A : c->actions)
-            if (A.kind == CMFP_ACTION_CTU)
-                for (int i = 0; i < A.n_states; ++i) list.push_back(A.states[i]);
+        // ghost cells of every CTU state (stage B FillPatch, MFP_advance.cpp:209); the flux kernels
+        // write the ping-pong partners, so all fills can go first
         int r;
         if ((r = fill_patch_many(c, list))) return r;
     }
-    for (const auto& A : c->actions) {
-        if (A.kind != CMFP_ACTION_CTU) continue;
-        for (int i = 0; i < A.n_states; ++i) {
-            StateRT& s = c->states[A.states[i]];
-            int r;
-            if ((r = dalloc(c, &s.alt, s.sp.nc * c->g.sc))) return r;
-            // a hydro state no source action touches afterwards: the CTU kernel is the last writer of
-            // the step and also leaves the CFL reduction of what it wrote
-            bool reduce = s.sp.kind == CMFP_STATE_HYDRO;
-            if (src >= 0) {
-                const cmfp_action_desc& SA = c->actions[src];
-                for (int q = 0; q < SA.n_states - 1; ++q)
-                    if (SA.states[q] == A.states[i]) reduce = false;
-            }
-            unsigned long long* slots = nullptr;
-            if (reduce) {
-                slots = reinterpret_cast<unsigned long long*>(c->d_part + (size_t)A.states[i] * CMFP_RED_BLOCKS);
-                HIPCHK(c, hipMemsetAsync(slots, 0, 256 * sizeof(unsigned long long), c->stream));
-            }
-            {
-                ProfScope prof(c, s.sp.kind == CMFP_STATE_HYDRO ? CMFP_PROF_CTU_HYDRO : CMFP_PROF_CTU_FIELD);
-                if (tiled[A.states[i]]) {
-                    c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, A.corner_transport, dt, c->touches, c->d_err, slots, c->stream);
-                } else {
-                    const Ptr3 F1{{c->gF1[0], c->gF1[1], c->gF1[2]}}, F2{{c->gF2[0], c->gF2[1], c->gF2[2]}};
-                    c->L->ctu_gather(c->g, s.sp, s.new_data, s.alt, F1, F2, A.corner_transport, dt, c->touches, c->d_err, slots,
-                                     c->stream);
-                }
-            }
-            if (reduce) {
-                c->L->reduce_final(reinterpret_cast<const double*>(slots), 256, 1, c->d_red + A.states[i], c->stream);
-                c->red_valid[A.states[i]] = 1;
-            }
-            std::swap(s.new_data, s.alt);
+    for (size_t q = 0; q < list.size(); ++q) {
+        StateRT& s = c->states[list[q]];
+        ProfScope prof(c, slot_of(s), c->stream, !overlap);
+        if (tiled[list[q]])
+            c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], overlap ? 2 : 0,
+                            c->stream);
+        else
+            c->L->ctu_gather(c->g, s.sp, s.new_data, s.alt, F1, F2, ctu_flag[q], dt, c->touches, c->d_err, slots[q], c->stream);
+    }
+    if (overlap) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_int, 0));
+    for (size_t q = 0; q < list.size(); ++q) {
+        StateRT& s = c->states[list[q]];
+        if (slots[q]) {
+            c->L->reduce_final(reinterpret_cast<const double*>(slots[q]), 256, 1, c->d_red + list[q], c->stream);
+            c->red_valid[list[q]] = 1;
         }
+        std::swap(s.new_data, s.alt);
     }
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
@@ -696,6 +734,12 @@ int cmfp_destroy(cmfp_context* c) {
             (void)hipEventDestroy(pr.second);
         }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->stream2) {
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamDestroy(c->stream2);
+        (void)hipEventDestroy(c->ev_src);
+        (void)hipEventDestroy(c->ev_int);
+    }
     for (double* p : c->allocs) (void)hipFree(p);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_red) (void)hipFree(c->d_red);
@@ -952,6 +996,7 @@ int cmfp_profile_read(cmfp_context* c, int slot, long long* launches, double* to
     if ((r = check_ctx(c))) return r;
     if (slot < 0 || slot >= CMFP_PROF_NSLOTS || !launches || !total_ms) return fail(c, CMFP_ERR_INVALID, "bad profile slot");
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     double ms = 0;
     for (auto& pr : c->prof[slot]) {
         float t = 0;
@@ -960,9 +1005,10 @@ int cmfp_profile_read(cmfp_context* c, int slot, long long* launches, double* to
         c->ev_pool.push_back(pr.first);
         c->ev_pool.push_back(pr.second);
     }
-    *launches = (long long)c->prof[slot].size();
+    *launches = (long long)c->prof[slot].size() - c->prof_uncounted[slot];
     *total_ms = ms;
     c->prof[slot].clear();
+    c->prof_uncounted[slot] = 0;
     return CMFP_OK;
 }
 
@@ -972,6 +1018,12 @@ int cmfp_set_exchange_callback(cmfp_context* c, cmfp_exchange_fn fn, void* user)
     c->exchange_user = user;
     return CMFP_OK;
 }
+int cmfp_set_overlap(cmfp_context* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return CMFP_ERR_INVALID;
+    c->overlap = mode;
+    return CMFP_OK;
+}
+
 int cmfp_set_exchange_batched(cmfp_context* c, int on) {
     if (!c) return CMFP_ERR_INVALID;
     c->exchange_batched = on != 0;

@@ -52,10 +52,40 @@ struct FaceBC {
     int rule[2][2][10];  // FILL_SKIP / FILL_EVEN / FILL_ODD per primitive comp
 };
 
+// Which tiles a launch covers.  part 0: all gx x gy tiles.  The other two split the tile grid for
+// halo/compute overlap: part 1 = the tiles [ix0, ix1] x [iy0, iy1] whose whole stencil footprint lies
+// in valid cells (they can run while ghost cells are still in flight), part 2 = the frame around them.
+struct TileSel {
+    int part, gx, gy, ix0, ix1, iy0, iy1, n;  // n: tiles in this launch
+};
+__device__ __forceinline__ void tile_of(const TileSel& s, int t, int& tix, int& tiy) {
+    if (s.part == 0) {
+        tix = t % s.gx;
+        tiy = t / s.gx;
+    } else if (s.part == 1) {
+        const int w = s.ix1 - s.ix0 + 1;
+        tix = s.ix0 + t % w;
+        tiy = s.iy0 + t / w;
+    } else {
+        const int rows_b = s.iy0 + (s.gy - 1 - s.iy1);  // full tile rows below and above the interior
+        if (t < rows_b * s.gx) {
+            const int ry = t / s.gx;
+            tix = t - ry * s.gx;
+            tiy = ry < s.iy0 ? ry : s.iy1 + 1 + (ry - s.iy0);
+        } else {
+            const int u = t - rows_b * s.gx;
+            const int cols_b = s.ix0 + (s.gx - 1 - s.ix1);
+            const int ry = u / cols_b, cx = u - ry * cols_b;
+            tiy = s.iy0 + ry;
+            tix = cx < s.ix0 ? cx : s.ix1 + 1 + (cx - s.ix0);
+        }
+    }
+}
+
 template <class Phys, int BX, int BY, bool HAS_BC, bool REDUCE>
 __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
                                                    double* __restrict__ Uout, int do_ctu, double dt, FaceBC bc, int* err,
-                                                   int gx, int nblk, unsigned long long* red) {
+                                                   TileSel sel, unsigned long long* red) {
     constexpr int NQ = Phys::NQ, NC = Phys::NC, NF = Phys::NF, RECON = Phys::RECON;
     constexpr int SL = ReconTraits<RECON>::SL, H = SL / 2;
     constexpr int TX = BX - 2, TY = BY - 2;
@@ -76,10 +106,12 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8
     // share one), each with its own L2.  Give every XCD a contiguous band of tile rows so
     // that the halo overlap of neighbouring tiles is served by that XCD's L2 instead of HBM.
-    const int per = (nblk + 7) >> 3;
+    const int per = (sel.n + 7) >> 3;
     const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (tile >= nblk) return;
-    const int i0 = (tile % gx) * TX, j0 = (tile / gx) * TY;
+    if (tile >= sel.n) return;
+    int tix, tiy;
+    tile_of(sel, tile, tix, tiy);
+    const int i0 = tix * TX, j0 = tiy * TY;
     const int i = i0 - 1 + tx, j = j0 - 1 + ty;  // this thread's cell
     const int n0 = g.n[0], n1 = g.n[1];
     const double gm1 = Phys::IS_HYDRO ? Phys::gamma_of(P) - 1.0 : 0.0;
@@ -352,16 +384,27 @@ static FaceBC make_bc(const StatePhys& sp, const int touches[3][2]) {
 
 template <class Phys, int BX, int BY>
 static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhys& sp, const double* Uin, double* Uout,
-                    int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
-    if (!Uin) return 1;  // coverage probe
-    const int gx = (g.n[0] + BX - 3) / (BX - 2), gy = (g.n[1] + BY - 3) / (BY - 2);
-    const int nblk = gx * gy;
+                    int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, int part,
+                    hipStream_t st) {
+    if (!Uin && part == 0) return 1;  // coverage probe
+    constexpr int TX = BX - 2, TY = BY - 2, H = ReconTraits<Phys::RECON>::SL / 2;
+    TileSel sel;
+    sel.part = part;
+    sel.gx = (g.n[0] + TX - 1) / TX;
+    sel.gy = (g.n[1] + TY - 1) / TY;
+    // interior tiles: footprint [i0 - 1 - H, i0 + TX + H] inside [0, n - 1]
+    sel.ix0 = sel.iy0 = 1;
+    sel.ix1 = g.n[0] - 1 - H - TX >= 0 ? (g.n[0] - 1 - H - TX) / TX : -1;
+    sel.iy1 = g.n[1] - 1 - H - TY >= 0 ? (g.n[1] - 1 - H - TY) / TY : -1;
+    const int n_int = (sel.ix1 >= sel.ix0 && sel.iy1 >= sel.iy0) ? (sel.ix1 - sel.ix0 + 1) * (sel.iy1 - sel.iy0 + 1) : 0;
+    if (!Uin) return n_int > 0;  // split probe: is there an interior to overlap with?
+    sel.n = part == 0 ? sel.gx * sel.gy : part == 1 ? n_int : sel.gx * sel.gy - n_int;
+    if (sel.n <= 0) return 1;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
-    const dim3 grid(((nblk + 7) / 8) * 8), block(BX, BY);
+    const dim3 grid(((sel.n + 7) / 8) * 8), block(BX, BY);
     const FaceBC bc = make_bc(sp, touches);
-#define CMFP_LAUNCH(BC, RED)                                                                                          \
-    hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, BC, RED>), grid, block, 0, st, g, P, Uin, Uout, do_ctu, dt, bc, err, gx, \
-                       nblk, red)
+#define CMFP_LAUNCH(BC, RED) \
+    hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, BC, RED>), grid, block, 0, st, g, P, Uin, Uout, do_ctu, dt, bc, err, sel, red)
     if constexpr (Phys::IS_HYDRO) {
         if (red) {
             if (has_bc) CMFP_LAUNCH(true, true); else CMFP_LAUNCH(false, true);
@@ -392,14 +435,16 @@ extern "C" void cmfp_debug_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
+// part: 0 all tiles, 1 interior tiles, 2 the frame of boundary tiles (see TileSel).  Uin == nullptr:
+// part 0 probes coverage, part 1 probes whether the block has interior tiles.
 int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
-              const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
+              const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st) {
     if (g.dim != 2) return 0;
 #define HY(R, F)                                                                                                    \
     if (sp.recon == R && sp.flux == F)                                                                              \
-        return launch2d<HydroF<R, F>, CMFP_HBX, CMFP_HBY>(g, sp.hp, sp, Uin, Uout, do_ctu, dt, touches, err, red, st);
+        return launch2d<HydroF<R, F>, CMFP_HBX, CMFP_HBY>(g, sp.hp, sp, Uin, Uout, do_ctu, dt, touches, err, red, part, st);
 #define FI(R)                                                                                                       \
-    if (sp.recon == R) return launch2d<FieldF<R>, CMFP_FBX, CMFP_FBY>(g, sp.fp, sp, Uin, Uout, do_ctu, dt, touches, err, red, st);
+    if (sp.recon == R) return launch2d<FieldF<R>, CMFP_FBX, CMFP_FBY>(g, sp.fp, sp, Uin, Uout, do_ctu, dt, touches, err, red, part, st);
     if (sp.kind == 0) {
         HY(1, 0) HY(1, 1) HY(1, 2) HY(2, 0) HY(2, 1) HY(2, 2) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)
     } else {

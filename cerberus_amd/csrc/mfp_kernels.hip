@@ -1004,7 +1004,7 @@ static int l_leaf_prim2cons(long n, double mass, double gamma, const double* Q, 
 
 // defined in mfp_fused.hip
 int ctu_fused(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
-              const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
+              const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t);
 #define CMFP_GATHER_DECL(D)                                                                                          \
     int ctu_gather_##D(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2, \
                        int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t);

@@ -115,7 +115,7 @@ struct Launchers {
     void (*pack)(const Geo&, int nc, int ngs, double* A, int d, int side, double* buf, int unpack, hipStream_t);
     // fused paths (return 0 when the option set is not covered)
     int (*ctu_fused)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
-                     const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
+                     const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t);
     int (*source_fused)(const Geo&, const SourceArgs&, double dt, int reduce, hipStream_t);
     // tile-free fused CTU update for any dimensionality (mfp_gather.hip); F1 / F2: face-flux scratch, 8 planes per direction
     int (*ctu_gather)(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,

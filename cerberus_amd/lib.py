@@ -42,6 +42,7 @@ SYMBOLS = [
     ("cmfp_profile_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), dp]),
     ("cmfp_set_exchange_callback", C.c_int, [C.c_void_p, EXCHANGE_FN, C.c_void_p]),
     ("cmfp_set_exchange_batched", C.c_int, [C.c_void_p, C.c_int]),
+    ("cmfp_set_overlap", C.c_int, [C.c_void_p, C.c_int]),
     ("cmfp_fill_patch", C.c_int, [C.c_void_p, C.c_int]),
     ("cmfp_halo_count", C.c_longlong, [C.c_void_p, C.c_int, C.c_int]),
     ("cmfp_halo_pack", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -41,7 +41,7 @@ def coords_rank(c, grid):
 
 class MFP:
     def __init__(self, problem, device=0, rank=0, world=1, stream=0, fused=True, pg=None, exchange_device=None,
-                 batched_exchange=True):
+                 batched_exchange=True, overlap=1):
         self.L = lib.load()
         self.p = problem if isinstance(problem, Problem) else Problem(problem)
         p = self.p
@@ -68,6 +68,7 @@ class MFP:
                 msg = "no HIP device visible: the hyperbolic update has no CPU fallback"
             raise lib.CmfpError(rc, msg)
         self.L.cmfp_set_fused(self.h, int(fused))
+        self._chk(self.L.cmfp_set_overlap(self.h, int(overlap)))
         self.shape = tuple(self.block_n[::-1])
         self.time, self.dt, self.step = 0.0, None, 0
         self._cb = None

@@ -252,6 +252,13 @@ int cmfp_set_exchange_callback(cmfp_context* ctx, cmfp_exchange_fn fn, void* use
  * FillPatch is per state, MFP_action.cpp:59; the data moved is the same). */
 #define CMFP_ALL_STATES (-1)
 int cmfp_set_exchange_batched(cmfp_context* ctx, int on);
+/* Halo/compute overlap inside cmfp_advance (fused 2-D Strang step).  1 (default): where the block is
+ * split between ranks, the flux update of the interior tiles runs on a second, library-owned stream
+ * while the ghost layers are packed, exchanged (callback) and unpacked on the context's stream; the
+ * frame of boundary tiles follows the fill.  0: one launch per state after the fill.  2: split the
+ * launches even on an unsplit block (testing).  Results are identical in all modes.  The exchange
+ * callback must only enqueue work on, or synchronise with, the context's stream. */
+int cmfp_set_overlap(cmfp_context* ctx, int mode);
 int cmfp_fill_patch(cmfp_context* ctx, int state);
 /* Number of doubles in one packed face of `state` normal to `dim`. */
 long long cmfp_halo_count(const cmfp_context* ctx, int state, int dim);

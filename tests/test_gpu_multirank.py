@@ -41,6 +41,8 @@ def _cfg(which):
     from cerberus_amd import problems
     if which == "ot":
         return problems.orszag_tang_two_fluid_2d(32)
+    if which == "ot96":
+        return problems.orszag_tang_two_fluid_2d(96)      # 48^2 blocks: interior tiles overlap the exchange
     if which == "gem":
         return problems.gem_reconnection_2d(32, 32)
     return problems.richtmyer_meshkov_3d(16, 16, 16)     # 3-D: gather kernels, 1x2x2 blocks
@@ -54,7 +56,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,which,batched", [(2, "ot", True), (4, "ot", True), (4, "ot", False), (4, "gem", True),
+@pytest.mark.parametrize("world,which,batched", [(2, "ot", True), (4, "ot", True), (4, "ot", False), (4, "gem", True), (4, "ot96", True), (2, "ot96", False),
                                                  (4, "rmi3d", True)])
 def test_decomposed_run_equals_single_rank(world, which, batched):
     import torch.multiprocessing as mp

@@ -48,3 +48,20 @@ def test_nstep_parity_fast(oracle, case, fused):
         a, b = m.download(s), ref.get_state(s)
         assert rel_linf(a, b) <= TOL_FAST, (name, P.state_names[s], rel_linf(a, b))
     m.close()
+
+
+@pytest.mark.parametrize("case", [1, 2, 3])
+def test_split_launches_identical(oracle, case):
+    """overlap=2: interior tiles on the second stream + frame of boundary tiles after the fill,
+    on an unsplit block; must equal the oracle bit for bit like the single launch."""
+    name, cfg, steps = small_cases()[case]
+    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    ref = oracle.OracleSim(P)
+    dts_ref = ref.run(steps)
+    m = _gpu(P, overlap=2)
+    dts = m.run(steps)
+    assert m.last_advance_path() == 1
+    assert dts == dts_ref
+    for s in range(m.n_states):
+        assert np.array_equal(m.download(s), ref.get_state(s)), (name, P.state_names[s])
+    m.close()
