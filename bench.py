@@ -74,8 +74,21 @@ def cpu_baseline(workload, seconds=12.0):
         if time.perf_counter() - t0 >= seconds:
             break
     el = time.perf_counter() - t0
-    return {"value": n * n * steps / el, "unit": "cell-updates/s", "cores": threads, "kind": "port",
-            "sample": f"{workload} {n}x{n}, max_grid_size 32, {steps} steps, {el:.1f} s"}
+    out = {"value": n * n * steps / el, "unit": "cell-updates/s", "cores": threads, "kind": "port",
+           "sample": f"{workload} {n}x{n}, max_grid_size 32, {steps} steps, {el:.1f} s"}
+    # the same port on one core (SURVEY.md §8d asks for both figures): a few steps of a 192^2 sample
+    O.lib().orc_set_threads(1)
+    n1 = 192
+    sim = O.OracleSim(build_problem(workload, n1, [1, 1, 1], abi.FP_STRICT), max_grid_size=32)
+    dt = sim.est_time_step()
+    sim.advance(dt)
+    t0, s1 = time.perf_counter(), 0
+    while s1 < 50 and time.perf_counter() - t0 < 5.0:
+        dt = min(sim.est_time_step(), 1.1 * dt)
+        sim.advance(dt)
+        s1 += 1
+    out["one_core_value"] = n1 * n1 * s1 / (time.perf_counter() - t0)
+    return out
 
 
 def main():
@@ -107,6 +120,20 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    def hbm_copy_gbs():
+        """attainable HBM bandwidth of this device: a 1 GiB device-to-device copy (read + write bytes)"""
+        a = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+        b_ = torch.empty_like(a)
+        b_.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b_.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        return 10 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
     fp_mode = abi.FP_FAST if args.fp == "fast" else abi.FP_STRICT
     dim = 3 if args.workload == "rmi_3d" else 2
@@ -159,9 +186,11 @@ def main():
                 key = f"{args.workload}:{args.n}"
                 if tj.get(key):
                     traffic = tj[key]["ctu_hydro_bytes_per_launch"]
+            copy_gbs = hbm_copy_gbs()
             roof = {"bound": "hbm", "kernel": "k_ctu2d<HydroF<minmod,HLLC>> (fused CTU update of one hydro state)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms / launches,
+                    "traffic": traffic, "attainable_copy_GBs": copy_gbs, "frac_of_attainable": achieved / copy_gbs,
+                    "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms / launches,
                     "launches": launches}
         step_bytes = ALGO_BYTES[args.workload] * cells_per_gpu
         out = {
