@@ -19,7 +19,7 @@ FLUX = {"HLLC": 0, "HLLE": 1, "HLLE/HLLC": 2, "RankineHugoniot": 10}
 BC_BOGUS, BC_REFLECT_ODD, BC_INT_DIR, BC_REFLECT_EVEN, BC_FOEXTRAP, BC_EXT_DIR, BC_HOEXTRAP = (
     -666, -1, 0, 1, 2, 3, 4)
 
-ACTION = {"CTU": 0, "plasma5": 1, "Lorentz": 2}
+ACTION = {"CTU": 0, "plasma5": 1, "Lorentz": 2, "collisions_rambo": 3}
 SOLVER = {"explicit": 0, "implicit": 1}
 TIME_INTEGRATOR = {"euler": 0, "RK2": 1, "strang": 2}
 FP_STRICT, FP_FAST = 0, 1
@@ -45,6 +45,7 @@ class Params(C.Structure):
         ("cfl", C.c_double),
         ("time_integrator", C.c_int),
         ("fp_mode", C.c_int),
+        ("n0", C.c_double),
     ]
 
 
@@ -59,6 +60,7 @@ class StateDesc(C.Structure):
         ("shock_threshold", C.c_double),
         ("div_transport", C.c_double),
         ("div_damping", C.c_double),
+        ("effective_zero", C.c_double),
         ("bc", ((C.c_int * 2) * MAX_DIM) * MAX_COMP),
     ]
 
@@ -70,4 +72,5 @@ class ActionDesc(C.Structure):
         ("solver", C.c_int),
         ("n_states", C.c_int),
         ("states", C.c_int * MAX_ACTION_STATES),
+        ("cross_sections", (C.c_double * MAX_ACTION_STATES) * MAX_ACTION_STATES),
     ]

@@ -16,7 +16,8 @@ import numpy as np
 from . import abi, bc
 
 DEFAULTS = dict(lightspeed=-1.0, beta=1.0, skin_depth=1.0, Larmor=-1.0, Debye=-1.0, cfl=0.0,
-                time_integration_scheme="strang", force_dt=0.0)
+                time_integration_scheme="strang", force_dt=0.0,
+                ref_length=1.0, ref_density=1.0, ref_mass=1.0, ref_temp=-1.0, ref_lightspeed=299792458.0)  # default.lua:12-16
 
 HYDRO_PRIM = ["rho", "x_vel", "y_vel", "z_vel", "p", "T", "gamma", "cp"]   # MFP_hydro.cpp:21-30
 FIELD_CONS = ["x_D", "y_D", "z_D", "x_B", "y_B", "z_B", "phi", "psi", "mu", "ep"]  # MFP_field.cpp:20-31
@@ -27,9 +28,16 @@ def update_ref(cfg):
     """MFP::update_ref (MFP_config.cpp:374-457): lightspeed, Larmor, Debye."""
     g = dict(DEFAULTS)
     g.update({k: cfg[k] for k in DEFAULTS if k in cfg})
+    x_ref, rho_ref, m_ref, T_ref, c_ref = g["ref_length"], g["ref_density"], g["ref_mass"], g["ref_temp"], g["ref_lightspeed"]
+    n0 = (rho_ref / m_ref) * x_ref * x_ref * x_ref   # :390-392
+    kB = 1.38064852e-23
     c = g["lightspeed"]
-    if not c > 0:
-        raise ValueError("lightspeed must be set (ref_temp scaling is outside the built path)")
+    if T_ref > 0 and c > 0:
+        raise ValueError("ref_temp and lightspeed both set, only set one")   # :398
+    if T_ref > 0:
+        c = c_ref / math.sqrt(kB * T_ref / m_ref)     # :400-404
+    elif not c > 0:
+        raise ValueError("Either ref_temp or lightspeed need to be set, only set one")
     Larmor, Debye, beta, skin = g["Larmor"], g["Debye"], g["beta"], g["skin_depth"]
     if Larmor > 0 and Debye > 0:                    # :420-421, case 1
         skin = Debye * c
@@ -39,7 +47,7 @@ def update_ref(cfg):
         Larmor = math.sqrt(beta / 2.0) * skin
     else:
         raise ValueError("plasma parameters not set")
-    return dict(lightspeed=c, Larmor=Larmor, Debye=Debye, beta=beta, skin_depth=skin)
+    return dict(lightspeed=c, Larmor=Larmor, Debye=Debye, beta=beta, skin_depth=skin, n0=n0, x_ref=x_ref)
 
 
 class Problem:
@@ -83,6 +91,7 @@ class Problem:
         p.cfl = self.cfl
         p.time_integrator = abi.TIME_INTEGRATOR[self.scheme]
         p.fp_mode = self.fp_mode
+        p.n0 = self.ref["n0"]
         return p
 
     def state_descs(self):
@@ -92,6 +101,7 @@ class Problem:
             d = arr[i]
             d.reconstruction = abi.RECON[sd["reconstruction"]]
             d.shock_threshold = -1.0
+            d.effective_zero = float(sd.get("effective_zero", 1e-14))   # MFP_eulerian.cpp:62
             if sd["type"] == "hydro":
                 d.kind = abi.STATE_HYDRO
                 gas = sd["gas"]
@@ -144,6 +154,26 @@ class Problem:
                 if len(field) != 1:
                     raise ValueError(f"action '{name}' needs exactly one field state")
                 idx = species + field       # species in list order, field last (MFP_plasma5.cpp:35-55)
+            if ad["type"] == "collisions_rambo":
+                if any(self.cfg["states"][n]["type"] != "hydro" for n in names):
+                    raise ValueError(f"An invalid state has been defined for the Collisions source {name}")
+                # cross_sections = {a = {b = sigma}}: non-dimensionalised and cross-loaded
+                # (MFP_collisions_rambo.cpp:39-55); names that are not species of this action are skipped
+                for na, row in ad.get("cross_sections", {}).items():
+                    if na not in names:
+                        continue
+                    for nb, sigma in row.items():
+                        if nb not in names:
+                            continue
+                        ia, ib = names.index(na), names.index(nb)
+                        s = float(sigma) / (self.ref["x_ref"] * self.ref["x_ref"])
+                        a.cross_sections[ia][ib] = s
+                        a.cross_sections[ib][ia] = s
+                if not ad.get("cross_sections"):
+                    for n in names:
+                        if float(self.cfg["states"][n]["gas"]["charge"]) == 0.0:
+                            raise ValueError(f"cross sections for collisions involving neutral species '{n}' are "
+                                             f"required by action '{name}'")
             a.n_states = len(idx)
             for j, v in enumerate(idx):
                 a.states[j] = v

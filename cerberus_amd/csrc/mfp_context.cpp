@@ -269,6 +269,27 @@ SourceArgs source_args(cmfp_context* c, const cmfp_action_desc& A, bool on_new) 
     return a;
 }
 
+// constants of a collisions_rambo action (MFP_collisions_rambo.cpp:57-64)
+CollArgs coll_args(cmfp_context* c, const cmfp_action_desc& A) {
+    CollArgs k;
+    std::memset(&k, 0, sizeof(k));
+    k.on = 1;
+    for (int n = 0; n < A.n_states; ++n) {
+        const StateRT& s = c->states[A.states[n]];
+        k.m[n] = s.desc.mass;
+        k.q[n] = s.desc.charge;
+        k.gamma[n] = s.desc.gamma;
+        k.ez[n] = s.desc.effective_zero;
+        for (int b = 0; b < A.n_states; ++b) k.ccs[n][b] = A.cross_sections[n][b];
+    }
+    const double n0 = c->params.n0, Debye = c->params.Debye;
+    k.c1 = 0.02116454531141366 / (n0 * std::pow(Debye, 4));
+    k.c2 = 0.4135669939329334;
+    k.c3 = 2.127692162140974 * n0;
+    k.err = c->d_err;
+    return k;
+}
+
 // Action::get_data MFP_action.cpp:15-102 for one (state, fill) option
 int get_data_one(cmfp_context* c, int si, bool fill) {
     StateRT& s = c->states[si];
@@ -300,6 +321,9 @@ int action_get_data(cmfp_context* c, int ai) {
     if (A.kind == CMFP_ACTION_CTU) {  // HydroCTU::get_data MFP_CTU_hydro.cpp:43-52
         for (int i = 0; i < A.n_states; ++i)
             if ((r = get_data_one(c, A.states[i], true))) return r;
+    } else if (A.kind == CMFP_ACTION_COLLISIONS_RAMBO) {  // Collisions::get_data MFP_collisions.cpp:83-93
+        for (int i = 0; i < A.n_states; ++i)
+            if ((r = get_data_one(c, A.states[i], false))) return r;
     } else {  // Plasma5::get_data MFP_plasma5.cpp:60-71, Lorentz::get_data MFP_lorentz.cpp:47-58
         if ((r = get_data_one(c, A.states[A.n_states - 1], false))) return r;
         for (int i = 0; i < A.n_states - 1; ++i)
@@ -311,6 +335,20 @@ int action_get_data(cmfp_context* c, int ai) {
 int action_calc_time_derivative(cmfp_context* c, int ai, double dt) {
     const cmfp_action_desc& A = c->actions[ai];
     if (A.kind == CMFP_ACTION_CTU) return CMFP_OK;  // Action::calc_time_derivative default (MFP_action.H:67-70)
+    if (A.kind == CMFP_ACTION_COLLISIONS_RAMBO) {  // Collisions::calc_time_derivative MFP_collisions.cpp:95-267
+        SourceArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.n_species = A.n_states;
+        for (int n = 0; n < A.n_states; ++n) {
+            StateRT& s = c->states[A.states[n]];
+            a.sp_U[n] = s.U;
+            a.sp_dU[n] = s.dU;
+            s.dU_status = Changed;
+        }
+        a.coll = coll_args(c, A);
+        c->L->collisions(c->g, a, dt, c->stream);
+        return CMFP_OK;
+    }
     SourceArgs a = source_args(c, A, false);
     for (int n = 0; n < A.n_states - 1; ++n) c->states[A.states[n]].dU_status = Changed;
     if (A.kind == CMFP_ACTION_PLASMA5) c->states[A.states[A.n_states - 1]].dU_status = Changed;  // MFP_plasma5.cpp:96,255
@@ -469,13 +507,16 @@ int advance_strang(cmfp_context* c, double dt) {
 // fused kernels cover (caller then takes the staged path), <0 on error.
 int advance_strang_fused(cmfp_context* c, double dt) {
     if (c->params.time_integrator != CMFP_TI_STRANG) return 0;
-    int n_src = 0, src = -1;
+    int n_src = 0, src = -1, coll = -1;
     std::vector<int> seen(c->states.size(), 0);
     for (size_t a = 0; a < c->actions.size(); ++a) {
         const cmfp_action_desc& A = c->actions[a];
         if (A.kind == CMFP_ACTION_CTU) {
             for (int i = 0; i < A.n_states; ++i)
                 if (seen[A.states[i]]++) return 0;
+        } else if (A.kind == CMFP_ACTION_COLLISIONS_RAMBO) {
+            if (coll >= 0) return 0;
+            coll = (int)a;
         } else {
             ++n_src;
             src = (int)a;
@@ -483,6 +524,14 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         }
     }
     if (n_src > 1) return 0;
+    if (coll >= 0) {
+        // the collisions are evaluated inside the source kernel: same species, same order
+        if (src < 0) return 0;
+        const cmfp_action_desc &S = c->actions[src], &K = c->actions[coll];
+        if (K.n_states != S.n_states - 1) return 0;
+        for (int n = 0; n < K.n_states; ++n)
+            if (K.states[n] != S.states[n]) return 0;
+    }
     // probe coverage (null launches): the tiled 2-D kernel where it applies, else the gather kernels
     std::vector<char> tiled(c->states.size(), 0);
     bool any_gather = false;
@@ -509,6 +558,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         }
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
+        if (coll >= 0) a.coll = coll_args(c, c->actions[coll]);
         ProfScope prof(c, CMFP_PROF_SOURCE);
         if (!c->L->source_fused(c->g, a, 0.5 * dt, 0, c->stream)) return 0;
     }
@@ -590,6 +640,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     }
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
+        if (coll >= 0) a.coll = coll_args(c, c->actions[coll]);
         ProfScope prof(c, CMFP_PROF_SOURCE);
         // last kernel of the step: it also leaves the CFL reductions of what it wrote
         c->L->source_fused(c->g, a, 0.5 * dt, 1, c->stream);
@@ -707,6 +758,14 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
         for (int i = 0; i < A.n_states; ++i)
             if (A.states[i] < 0 || A.states[i] >= n_states) return fail(c, CMFP_ERR_INVALID, "bad action state index");
         if (A.kind == CMFP_ACTION_CTU) continue;
+        if (A.kind == CMFP_ACTION_COLLISIONS_RAMBO) {
+            if (A.n_states > 4) return fail(c, CMFP_ERR_INVALID, "at most 4 species per collisions action");
+            for (int i = 0; i < A.n_states; ++i)
+                if (c->states[A.states[i]].sp.kind != CMFP_STATE_HYDRO)  // MFP_collisions.cpp:35
+                    return fail(c, CMFP_ERR_INVALID, "An invalid state has been defined for the Collisions source");
+            if (!(params->n0 > 0.0)) return fail(c, CMFP_ERR_INVALID, "collisions_rambo needs params.n0 > 0");
+            continue;
+        }
         if (A.kind != CMFP_ACTION_PLASMA5 && A.kind != CMFP_ACTION_LORENTZ) return fail(c, CMFP_ERR_INVALID, "unknown action kind");
         if (A.n_states - 1 > 4) return fail(c, CMFP_ERR_INVALID, "at most 4 species per source action");
         if (c->states[A.states[A.n_states - 1]].sp.kind != CMFP_STATE_FIELD)

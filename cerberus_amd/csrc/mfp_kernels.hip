@@ -341,6 +341,113 @@ CMFP_DEV void plasma5_explicit_cell(const SourceArgs& a, const SourceCoef& kf, d
     fdU[4] = -fU[F_PSI] * kf.f3;
 }
 
+// One cell of Collisions::calc_time_derivative (MFP_collisions.cpp:158-246) with
+// CollisionsRambo::calc_update (MFP_collisions_rambo.cpp:68-126), single-species states
+// (alpha = 1).  out[s][c] is what the reference adds to dU: (U + dt * delta) - U.
+template <int NS>
+CMFP_DEV void collisions_rambo_cell(const CollArgs& ca, double dt, const double (*sU)[5], double (*out)[5]) {
+    double rho[NS], m[NS], q[NS], T[NS], q2[NS], nd[NS], vel[NS][3], delta[NS][5];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        double Tn = 0.0;
+        if (!(sU[n][0] < ca.ez[n])) {  // gas->cons2prim, MFP_collisions.cpp:166-171
+            double Q[5];
+            GasP G{ca.m[n], ca.q[n], ca.gamma[n]};
+            bool ok = hydro_cons2prim(G, sU[n], Q);
+            const double rhoinv = f_rcp(sU[n][0]);
+            Tn = Q[H_P] * rhoinv * ca.m[n];  // MFP_thermally_perfect_gas.cpp:207
+            if (!ok) *ca.err = 1;
+        }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) delta[n][c] = 0.0;
+        if (sU[n][0] > ca.ez[n]) {
+            rho[n] = 1.0 * sU[n][0];
+            m[n] = ca.m[n];
+            q[n] = ca.q[n];
+            T[n] = Tn;
+            q2[n] = q[n] * q[n];
+            nd[n] = f_div(rho[n], m[n]);
+            const double i_rho = f_rcp(rho[n]);
+            vel[n][0] = 1.0 * sU[n][1] * i_rho;
+            vel[n][1] = 1.0 * sU[n][2] * i_rho;
+            vel[n][2] = 1.0 * sU[n][3] * i_rho;
+        } else {
+            rho[n] = m[n] = q[n] = T[n] = q2[n] = nd[n] = 0.0;
+            vel[n][0] = vel[n][1] = vel[n][2] = 0.0;
+        }
+    }
+    const double lnC = 10.0;
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+#pragma unroll
+        for (int b = a + 1; b < NS; ++b) {
+            const double m_ab = f_div(m[a] * m[b], m[a] + m[b]);
+            double du2 = 0.0, du[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                du[i] = vel[b][i] - vel[a][i];
+                du2 += du[i] * du[i];
+            }
+            double nu;
+            if ((q[a] != 0) && (q[b] != 0)) {
+                const double coeff_1 = ca.c1 * f_div(q2[a] * q2[b] * lnC, m_ab * m[a]);
+                const double x = ca.c2 * du2 + f_div(T[a], m[a]) + f_div(T[b], m[b]);
+#ifdef CMFP_FASTMATH
+                const double p15 = f_rsqrt(x) * f_rcp(x);  // x^-1.5
+#else
+                const double p15 = pow(x, -1.5);
+#endif
+                nu = nd[b] * coeff_1 * p15;
+            } else {
+                const double coeff_2 = f_div(m[b] * ca.ccs[a][b], m[a] + m[b]);
+                nu = nd[b] * coeff_2 * ca.c3 * f_sqrt(f_div(T[a], m[a]) + f_div(T[b], m[b]));
+            }
+            const double S = 0.0;
+            double Qx = m_ab * nd[a] * nu * du2 + f_div(3 * rho[a] * nu, m[a] + m[b]) * (T[b] - T[a]);
+            double R[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                R[i] = rho[a] * nu * du[i];
+                Qx += R[i] * vel[a][i];
+            }
+            delta[a][0] += S;
+            delta[b][0] -= S;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                delta[a][1 + i] += R[i];
+                delta[b][1 + i] -= R[i];
+            }
+            delta[a][4] += Qx;
+            delta[b][4] -= Qx;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            double acc = sU[n][c] * 1.0;
+            acc += dt * delta[n][c];
+            out[n][c] = (0.0 + acc) - sU[n][c];
+        }
+}
+
+template <int NS>
+__global__ void k_collisions(Geo g, IBox box, SourceArgs a, double dt) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long c = g.at(i, j, k);
+    double sU[NS][5], out[NS][5];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int n = 0; n < 5; ++n) sU[s][n] = a.sp_U[s][c + n * g.sc];
+    collisions_rambo_cell<NS>(a.coll, dt, sU, out);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int n = 0; n < 5; ++n) a.sp_dU[s][c + n * g.sc] += out[s][n];
+}
+
 // One cell of Plasma5::implicit_solve (MFP_plasma5.cpp:324-448).  The
 // reference factors the dense 3(Ns+1) system with Eigen's ColPivHouseholderQR;
 // here the same linear system
@@ -533,7 +640,7 @@ __device__ __forceinline__ void st_plane(double* base, unsigned off, double v) {
     *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off) = v;
 }
 
-template <int NS, bool IMPL, bool REDUCE>
+template <int NS, bool IMPL, bool REDUCE, bool COLL>
 __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs a, SourceCoef kf, double dt) {
     const long npts = box.npts();
     double red_speed[NS];
@@ -574,6 +681,14 @@ __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs 
             plasma5_implicit_cell<NS>(a, kf, dt, f0, s0, sdU, fdU);
         else
             plasma5_explicit_cell<NS>(a, kf, dt, f0, s0, sdU, fdU);
+        if constexpr (COLL) {  // a collisions_rambo action over the same species adds to the same dU
+            double cd[NS][5];
+            collisions_rambo_cell<NS>(a.coll, dt, s0, cd);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) sdU[s][n] += cd[s][n + 1];
+        }
 #pragma unroll
         for (int n = 0; n < 10; ++n) f1[n] = f0[n];
         if (!a.lorentz_only) {
@@ -594,6 +709,14 @@ __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs 
             plasma5_implicit_cell<NS>(a, kf, dt, f1, s1, sdU, fdU);
         else
             plasma5_explicit_cell<NS>(a, kf, dt, f1, s1, sdU, fdU);
+        if constexpr (COLL) {
+            double cd[NS][5];
+            collisions_rambo_cell<NS>(a.coll, dt, s1, cd);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) sdU[s][n] += cd[s][n + 1];
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             double Un[5];
@@ -897,18 +1020,32 @@ static void l_source(const Geo& g, const SourceArgs& a, double dt, hipStream_t s
     case 4: l_source_n<4>(g, a, dt, st); break;
     }
 }
+static void l_collisions(const Geo& g, const SourceArgs& a, double dt, hipStream_t st) {
+    IBox b = valid_box(g);
+    switch (a.n_species) {
+    case 1: LAUNCH((k_collisions<1>), b.npts(), st, g, b, a, dt); break;
+    case 2: LAUNCH((k_collisions<2>), b.npts(), st, g, b, a, dt); break;
+    case 3: LAUNCH((k_collisions<3>), b.npts(), st, g, b, a, dt); break;
+    case 4: LAUNCH((k_collisions<4>), b.npts(), st, g, b, a, dt); break;
+    }
+}
 static unsigned red_blocks(long npts) { return (unsigned)std::min<long>(nblocks(npts), RED_BLOCKS); }
 
 template <int NS> static void l_source_rk2_n(const Geo& g, const SourceArgs& a, double dt, int reduce, hipStream_t st) {
     IBox b = valid_box(g);
     const unsigned nb = red_blocks(b.npts());
     const SourceCoef kf = source_coef(a, dt);
-#define RK2(I, R) hipLaunchKernelGGL((k_source_rk2<NS, I, R>), dim3(nb), dim3(TPB), 0, st, g, b, a, kf, dt)
+#define RK2(I, R, C) hipLaunchKernelGGL((k_source_rk2<NS, I, R, C>), dim3(nb), dim3(TPB), 0, st, g, b, a, kf, dt)
+#define RK2C(I, R) \
+    do {           \
+        if (a.coll.on) RK2(I, R, true); else RK2(I, R, false); \
+    } while (0)
     if (a.implicit) {
-        if (reduce) RK2(true, true); else RK2(true, false);
+        if (reduce) RK2C(true, true); else RK2C(true, false);
     } else {
-        if (reduce) RK2(false, true); else RK2(false, false);
+        if (reduce) RK2C(false, true); else RK2C(false, false);
     }
+#undef RK2C
 #undef RK2
     if (reduce) {
         for (int s = 0; s < NS; ++s)
@@ -1024,7 +1161,7 @@ const Launchers* launchers() {
     static const Launchers L = {l_prim,      l_recon,         l_face_bc,        l_fluxes,          l_correct,
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_fill_dim,        l_pack,
-                                ctu_fused,   l_source_fused,  l_ctu_gather, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
+                                ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
                                 l_leaf_prim2cons, l_reduce_final};
     return &L;
 }

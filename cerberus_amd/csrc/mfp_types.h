@@ -59,6 +59,16 @@ struct Ptr3 {
 };
 
 // species list of a plasma5 / Lorentz action
+// CollisionsRambo (actions/reactions/MFP_collisions_rambo.cpp): per-species constants, the species
+// being the hydro states of the action in list order
+struct CollArgs {
+    int on;
+    double m[4], q[4], gamma[4], ez[4];  // gas mass, charge, gamma; the state's effective_zero
+    double ccs[4][4];                     // cross sections / x_ref^2
+    double c1, c2, c3;                    // MFP_collisions_rambo.cpp:60-62
+    int* err;                             // device flag: primitive values outside of physical bounds
+};
+
 struct SourceArgs {
     int n_species;
     double* sp_U[4];   // species conserved data read
@@ -79,6 +89,7 @@ struct SourceArgs {
     double* part_dt;
     unsigned long long* out_speed[4];  // final words
     unsigned long long* out_dt;
+    CollArgs coll;  // a collisions_rambo action over the same species, evaluated with this source (fused step)
 };
 
 // ghost fill rule per component for one (dim, side)
@@ -117,6 +128,8 @@ struct Launchers {
     int (*ctu_fused)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
                      const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t);
     int (*source_fused)(const Geo&, const SourceArgs&, double dt, int reduce, hipStream_t);
+    // Collisions::calc_time_derivative on sp_U -> sp_dU of the first n_species entries (a.coll)
+    void (*collisions)(const Geo&, const SourceArgs&, double dt, hipStream_t);
     // tile-free fused CTU update for any dimensionality (mfp_gather.hip); F1 / F2: face-flux scratch, 8 planes per direction
     int (*ctu_gather)(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
                       int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t);

@@ -83,7 +83,7 @@ def kelvin_helmholtz_2d(n=2048, flux="HLLC", recon="minmod"):
     }
 
 
-def orszag_tang_two_fluid_2d(n=4096, solver="explicit", source="plasma5"):
+def orszag_tang_two_fluid_2d(n=4096, solver="explicit", source="plasma5", collisions=False):
     gam = 5 / 3
     c = 20.0
     L = 2 * math.pi
@@ -103,7 +103,7 @@ def orszag_tang_two_fluid_2d(n=4096, solver="explicit", source="plasma5"):
     src = {"type": source, "states": ["ion", "electron", "field"]}
     if source == "plasma5":
         src["solver"] = solver
-    return {
+    cfg = {
         "dim": 2, "n_cell": [n, n], "prob_lo": [0.0, 0.0], "prob_hi": [L, L], "is_periodic": [1, 1],
         "cfl": 0.3, "time_integration_scheme": "strang",
         "lightspeed": c, "skin_depth": 0.2, "beta": 1.0,
@@ -118,6 +118,41 @@ def orszag_tang_two_fluid_2d(n=4096, solver="explicit", source="plasma5"):
             "em_fluxes": {"type": "CTU", "corner_transport": True, "states": ["field"]},
             "hydro_fluxes": {"type": "CTU", "corner_transport": True, "states": ["ion", "electron"]},
             "plasma": src,
+        },
+    }
+    if collisions:
+        # ion-electron Coulomb collisions (CollisionsRambo) beside the Lorentz coupling; sorted before "plasma".
+        # n0 = n_ref x_ref^3 sets the collisionality: nu ~ 1 / (n0 Debye^4)
+        cfg["ref_density"] = 1.0e8
+        cfg["actions"]["collisions"] = {"type": "collisions_rambo", "states": ["ion", "electron"]}
+    return cfg
+
+
+def collisions_relaxation(n=4, neutral=False):
+    """Exec/testing/Collisions/Collisions.inputs: a carbon beam (A) relaxing on a carbon background (B)
+    through CollisionsRambo alone (no flux action), RK2 with a forced time step.  neutral=True swaps B for
+    a neutral gas so that the hard-sphere branch with the given cross section runs."""
+    kB, ep0, q0 = 1.38064852e-23, 8.85418782e-12, 1.60217662e-19
+    nd = 1e20 * 1e6
+    ref_length, ref_mass, ref_temp = 1e-3, 1.67e-24 / 1e3, 11604525.00617
+    ref_vel = math.sqrt(kB * ref_temp / ref_mass)
+    beam_velocity = 6.55e7 * 1e-2 / ref_vel
+    dD0 = math.sqrt((ep0 * kB * ref_temp) / (nd * q0 ** 2))
+    gas = lambda q: {"type": "thermally_perfect", "mass": 12.0, "charge": q, "gamma": 5 / 3}
+    return {
+        "dim": 2, "n_cell": [n, n], "prob_lo": [-1.0, -1.0], "prob_hi": [1.0, 1.0], "is_periodic": [1, 1],
+        "cfl": 0.5, "time_integration_scheme": "RK2", "force_dt": 0.0001,
+        "ref_length": ref_length, "ref_mass": ref_mass, "ref_temp": ref_temp, "ref_density": nd * ref_mass,
+        "Larmor": 1.0, "Debye": dD0 / ref_length,
+        "states": {
+            "A": {"type": "hydro", "gas": gas(6.0), "reconstruction": "centre", "flux": "HLLE",
+                  "value": {"nd": 0.1, "x_vel": beam_velocity, "p": 0.05}},
+            "B": {"type": "hydro", "gas": gas(0.0 if neutral else 6.0), "reconstruction": "centre", "flux": "HLLE",
+                  "value": {"nd": 1.0, "p": 0.5}},
+        },
+        "actions": {
+            "collisions": {"type": "collisions_rambo", "states": ["A", "B"],
+                           "cross_sections": {"A": {"B": 1.0e-20 if neutral else 1.0, "C": 1.0}}},
         },
     }
 
@@ -231,4 +266,5 @@ WORKLOADS = {
     "ot2f_2d": orszag_tang_two_fluid_2d,
     "gem_2d": gem_reconnection_2d,
     "rmi_3d": richtmyer_meshkov_3d,
+    "collisions": collisions_relaxation,
 }

@@ -72,8 +72,14 @@ typedef enum {
 } cmfp_bc;
 
 /* Action tags "CTU" (MFP_CTU_hydro.cpp:10), "plasma5" (MFP_plasma5.cpp:9),
- * "Lorentz" (MFP_lorentz.cpp). */
-typedef enum { CMFP_ACTION_CTU = 0, CMFP_ACTION_PLASMA5 = 1, CMFP_ACTION_LORENTZ = 2 } cmfp_action_kind;
+ * "Lorentz" (MFP_lorentz.cpp), "collisions_rambo"
+ * (actions/reactions/MFP_collisions_rambo.cpp:7). */
+typedef enum {
+    CMFP_ACTION_CTU = 0,
+    CMFP_ACTION_PLASMA5 = 1,
+    CMFP_ACTION_LORENTZ = 2,
+    CMFP_ACTION_COLLISIONS_RAMBO = 3
+} cmfp_action_kind;
 
 typedef enum { CMFP_SOLVER_EXPLICIT = 0, CMFP_SOLVER_IMPLICIT = 1 } cmfp_source_solver;
 
@@ -107,6 +113,7 @@ typedef struct {
     double cfl;
     int time_integrator; /* cmfp_time_integrator */
     int fp_mode;         /* cmfp_fp_mode          */
+    double n0;           /* MFP::n0 = n_ref x_ref^3 (MFP_config.cpp:390-392); collisions only */
 } cmfp_params;
 
 /* One Eulerian state, in the reference's sorted-name order
@@ -123,6 +130,7 @@ typedef struct {
     double shock_threshold; /* shock_detector.threshold (<=0: none)            */
     double div_transport;   /* field: c_h / c                                  */
     double div_damping;     /* field                                           */
+    double effective_zero;  /* states.<name>.effective_zero (MFP_eulerian.cpp:62), default 1e-14 */
     /* BCRec per conserved component: bc[comp][dim][0=lo,1=hi] (cmfp_bc).
      * hydro uses comps 0..4, field 0..9. */
     int bc[CMFP_MAX_COMP][CMFP_MAX_DIM][2];
@@ -135,8 +143,13 @@ typedef struct {
     int solver;           /* plasma5: cmfp_source_solver (MFP_plasma5.cpp:22-31) */
     int n_states;
     /* CTU: the states it transports.  plasma5/Lorentz: species in the order
-     * of the Lua 'states' list, then the field last. */
+     * of the Lua 'states' list, then the field last.  collisions_rambo: the
+     * hydro states (= species, single-species gases) in list order. */
     int states[CMFP_MAX_ACTION_STATES];
+    /* collisions_rambo: hard-sphere cross sections between species a and b of the
+     * list, already divided by x_ref^2 and symmetric (MFP_collisions_rambo.cpp:39-55);
+     * only pairs with a neutral partner use them. */
+    double cross_sections[CMFP_MAX_ACTION_STATES][CMFP_MAX_ACTION_STATES];
 } cmfp_action_desc;
 
 typedef struct cmfp_context cmfp_context;

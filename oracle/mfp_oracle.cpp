@@ -1223,6 +1223,9 @@ struct Sim {
         if (A.kind == CMFP_ACTION_CTU) {
             // HydroCTU::get_data  MFP_CTU_hydro.cpp:43-52
             for (int i = 0; i < A.n_states; ++i) options.push_back({A.states[i], 1});
+        } else if (A.kind == CMFP_ACTION_COLLISIONS_RAMBO) {
+            // Collisions::get_data MFP_collisions.cpp:83-93
+            for (int i = 0; i < A.n_states; ++i) options.push_back({A.states[i], 0});
         } else {
             // Plasma5::get_data MFP_plasma5.cpp:60-71 / Lorentz::get_data MFP_lorentz.cpp:47-58
             options.push_back({A.states[A.n_states - 1], 0});
@@ -1453,9 +1456,117 @@ struct Sim {
         }
     }
 
+    // Collisions::calc_time_derivative MFP_collisions.cpp:95-267 with CollisionsRambo::calc_update
+    // MFP_collisions_rambo.cpp:68-126; single-species states (alpha = 1, no tracers, no EB).
+    void collisions_rambo(int a, std::vector<UpdateData>& update, Real dt) {
+        const cmfp_action_desc& A = actions[a].desc;
+        const int n_species = A.n_states;
+        for (int n = 0; n < n_species; ++n) update[A.states[n]].dU_status = Changed;
+        // coefficients, MFP_collisions_rambo.cpp:57-64
+        const Real Debye = P.Debye, n0 = P.n0;
+        const Real c1 = 0.02116454531141366 / (n0 * pow(Debye, 4));
+        const Real c2 = 0.4135669939329334;
+        const Real c3 = 2.127692162140974 * n0;
+        const Real lnC = 10.0;
+        struct Info {
+            Real rho, m, q, T, q2, n, vel[3], delta[5];
+        };
+#pragma omp parallel for schedule(dynamic)
+        for (long b = 0; b < (long)boxes.size(); ++b) {
+            const Box& box = boxes[b];
+            Info sp[CMFP_MAX_ACTION_STATES];
+            Real U[CMFP_MAX_ACTION_STATES][5], Q[CMFP_MAX_ACTION_STATES][8];
+            for (int k = box.lo[2]; k <= box.hi[2]; ++k)
+                for (int j = box.lo[1]; j <= box.hi[1]; ++j)
+                    for (int i = box.lo[0]; i <= box.hi[0]; ++i) {
+                        for (int si = 0; si < n_species; ++si) {
+                            const StateDef& S = states[A.states[si]];
+                            for (int l = 0; l < 5; ++l) U[si][l] = update[A.states[si]].U[b](i, j, k, l);
+                            if (U[si][Density] < S.desc.effective_zero) {
+                                for (int l = 0; l < 8; ++l) Q[si][l] = 0.0;
+                            } else {
+                                gas_cons2prim(S.gas, U[si], Q[si]);
+                            }
+                        }
+                        for (int n = 0; n < n_species; ++n) {
+                            const StateDef& S = states[A.states[n]];
+                            Info& info = sp[n];
+                            for (int l = 0; l < 5; ++l) info.delta[l] = 0.0;
+                            const Real al = 1.0;  // get_alpha_fractions_from_prim, single species
+                            if (U[n][Density] > S.desc.effective_zero) {
+                                info.rho = al * U[n][Density];
+                                info.m = S.gas.mass;
+                                info.q = S.gas.charge;
+                                info.T = Q[n][Temp];
+                                info.q2 = info.q * info.q;
+                                info.n = info.rho / info.m;
+                                const Real i_rho = 1 / info.rho;
+                                info.vel[0] = al * U[n][Xmom] * i_rho;
+                                info.vel[1] = al * U[n][Ymom] * i_rho;
+                                info.vel[2] = al * U[n][Zmom] * i_rho;
+                            } else {
+                                info.rho = info.m = info.q = info.T = info.q2 = info.n = 0.0;
+                                info.vel[0] = info.vel[1] = info.vel[2] = 0.0;
+                            }
+                        }
+                        // calc_update
+                        for (int ia = 0; ia < n_species; ++ia) {
+                            Info& sda = sp[ia];
+                            for (int ib = ia + 1; ib < n_species; ++ib) {
+                                Info& sdb = sp[ib];
+                                const Real m_ab = (sda.m * sdb.m) / (sda.m + sdb.m);
+                                Real du2 = 0.0;
+                                Real du[3];
+                                for (int d = 0; d < 3; ++d) {
+                                    du[d] = sdb.vel[d] - sda.vel[d];
+                                    du2 += du[d] * du[d];
+                                }
+                                Real nu;
+                                if ((sda.q != 0) && (sdb.q != 0)) {
+                                    const Real coeff_1 = c1 * ((sda.q2 * sdb.q2 * lnC) / (m_ab * sda.m));
+                                    nu = sdb.n * coeff_1 * pow(c2 * du2 + sda.T / sda.m + sdb.T / sdb.m, -1.5);
+                                } else {
+                                    const Real coeff_2 = (sdb.m * A.cross_sections[ia][ib]) / (sda.m + sdb.m);
+                                    nu = sdb.n * coeff_2 * c3 * sqrt(sda.T / sda.m + sdb.T / sdb.m);
+                                }
+                                const Real S_ = 0.0;
+                                Real Qx = m_ab * sda.n * nu * du2 + 3 * sda.rho * nu / (sda.m + sdb.m) * (sdb.T - sda.T);
+                                Real R[3];
+                                for (int d = 0; d < 3; ++d) {
+                                    R[d] = sda.rho * nu * du[d];
+                                    Qx += R[d] * sda.vel[d];
+                                }
+                                sda.delta[Density] += S_;
+                                sdb.delta[Density] -= S_;
+                                for (int d = 0; d < 3; ++d) {
+                                    sda.delta[Xmom + d] += R[d];
+                                    sdb.delta[Xmom + d] -= R[d];
+                                }
+                                sda.delta[Eden] += Qx;
+                                sdb.delta[Eden] -= Qx;
+                            }
+                        }
+                        // accounting (:218-246): original amount * alpha + dt * delta, minus the original
+                        for (int si = 0; si < n_species; ++si) {
+                            Fab& U4 = update[A.states[si]].U[b];
+                            Fab& dU4 = update[A.states[si]].dU[b];
+                            for (int ci = 0; ci < 5; ++ci) {
+                                Real acc = U[si][ci] * 1.0;
+                                acc += dt * sp[si].delta[ci];
+                                Real sum = 0.0;
+                                sum += acc;
+                                dU4(i, j, k, ci) += sum - U4(i, j, k, ci);
+                            }
+                        }
+                    }
+        }
+    }
+
     void action_calc_time_derivative(int a, std::vector<UpdateData>& update, Real dt) {
         const cmfp_action_desc& A = actions[a].desc;
-        if (A.kind == CMFP_ACTION_PLASMA5) {
+        if (A.kind == CMFP_ACTION_COLLISIONS_RAMBO) {
+            collisions_rambo(a, update, dt);
+        } else if (A.kind == CMFP_ACTION_PLASMA5) {
             if (A.solver == CMFP_SOLVER_EXPLICIT)
                 plasma5_explicit(a, update, dt, false);
             else

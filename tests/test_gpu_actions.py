@@ -219,3 +219,41 @@ def test_full_size_properties():
     f.run(3)
     assert rel_linf(f.download(0), A) <= 1e-12
     f.close()
+
+
+# ---- collisions_rambo -------------------------------------------------------------------
+@pytest.mark.parametrize("neutral", [False, True])
+def test_collisions_relaxation_parity(oracle, neutral):
+    """Collisions alone, RK2 (stage-by-stage kernels).  STRICT: the hard-sphere branch (sqrt) is
+    bit-identical; the Coulomb branch calls pow(x, -1.5), where the device library and glibc may
+    differ in the last place, hence 1e-13."""
+    for mode, tol in ((abi.FP_STRICT, 0.0 if neutral else 1e-13), (abi.FP_FAST, 1e-12)):
+        P = config.Problem(problems.collisions_relaxation(8, neutral), fp_mode=mode)
+        ref = oracle.OracleSim(P)
+        m = _gpu(P)
+        for _ in range(40):
+            ref.advance(1e-4)
+            m.advance(1e-4)
+        for s in range(2):
+            assert rel_linf(m.download(s), ref.get_state(s)) <= tol, (neutral, mode, s)
+        m.close()
+
+
+def test_collisions_with_plasma5_fused(oracle):
+    """two-fluid Orszag-Tang with ion-electron collisions beside plasma5: the fused Strang step
+    evaluates both sources in one kernel; the staged path runs them as two actions."""
+    cfg = problems.orszag_tang_two_fluid_2d(32, collisions=True)
+    for mode, tol in ((abi.FP_STRICT, 1e-13), (abi.FP_FAST, 1e-12)):
+        P = config.Problem(cfg, fp_mode=mode)
+        ref = oracle.OracleSim(P)
+        ref.run(6)
+        refc = oracle.OracleSim(config.Problem(problems.orszag_tang_two_fluid_2d(32), fp_mode=mode))
+        refc.run(6)
+        assert rel_linf(ref.get_state(0), refc.get_state(0)) > 1e-6      # the collisions do something here
+        for fused in (False, True):
+            m = _gpu(P, fused=fused)
+            m.run(6)
+            assert m.last_advance_fused() == fused
+            for s in range(3):
+                assert rel_linf(m.download(s), ref.get_state(s)) <= tol, (mode, fused, P.state_names[s])
+            m.close()

@@ -197,3 +197,29 @@ def test_implicit_and_explicit_sources_agree_for_small_dt(oracle):
     # plasma action is index 2; first-order agreement of the momentum source
     da, db = a.action_dU(2, dt, s), b.action_dU(2, dt, s)
     assert np.abs(da[1:4] - db[1:4]).max() < 1e-3 * np.abs(da[1:4]).max()
+
+
+# ---- collisions_rambo (no reference fixture: parity unpinned; physics properties) --------
+@pytest.mark.parametrize("neutral", [False, True])
+def test_collisions_conserve_and_equilibrate(oracle, neutral):
+    """Exec/testing/Collisions: the beam and the background exchange momentum and energy only
+    with each other (R and Q enter with opposite signs, MFP_collisions_rambo.cpp:112-123) and
+    relax to a common velocity and temperature."""
+    from cerberus_amd import config, problems
+    P = config.Problem(problems.collisions_relaxation(4, neutral))
+    sim = oracle.OracleSim(P)
+    U0 = [sim.get_state(s).copy() for s in range(2)]
+    for _ in range(300):
+        sim.advance(1e-4)
+    U1 = [sim.get_state(s) for s in range(2)]
+    tot0, tot1 = U0[0] + U0[1], U1[0] + U1[1]
+    assert np.abs(tot1 - tot0).max() <= 1e-12 * np.abs(tot0).max()
+    assert np.array_equal(U1[0][0], U0[0][0]) and np.array_equal(U1[1][0], U0[1][0])   # S = 0: densities untouched
+
+    def uT(U):
+        rho, mx, E = U[0], U[1], U[4]
+        return mx / rho, (E - 0.5 * mx * mx / rho) * (2 / 3) / rho * 12.0
+    (ua, Ta), (ub, Tb) = uT(U1[0]), uT(U1[1])
+    assert np.abs(ua - ub).max() < 1e-2 * np.abs(uT(U0[0])[0]).max()
+    assert np.abs(Ta - Tb).max() < 2e-2 * Ta.max()
+    assert Ta.min() > uT(U0[0])[1].max()          # the beam's drift energy became heat
