@@ -28,12 +28,25 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert getattr(L, n) is not None
 
 
-def test_struct_sizes_match_header_layout():
-    # layouts are plain C: ints and doubles in declaration order
-    assert C.sizeof(abi.Geometry) == 4 + 12 + 4 + 24 + 24 + 12 + 12 + 12  # int, pad to 8 before doubles
-    assert C.sizeof(abi.Params) == 4 * 8 + 2 * 4
-    assert C.sizeof(abi.ActionDesc) == 4 * 4 + 8 * 4
-    assert C.sizeof(abi.StateDesc) == 3 * 4 + 4 + 6 * 8 + 10 * 3 * 2 * 4
+def test_struct_sizes_match_header_layout(tmp_path):
+    """sizeof / offsetof of every POD of include/cerberus_mfp.h as gcc lays them out against the ctypes mirror."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "cerberus_mfp.h"\n'
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(cmfp_geometry), sizeof(cmfp_params),"
+        " sizeof(cmfp_state_desc), sizeof(cmfp_action_desc), offsetof(cmfp_params, n0),"
+        " offsetof(cmfp_state_desc, effective_zero), offsetof(cmfp_state_desc, bc),"
+        " offsetof(cmfp_action_desc, cross_sections));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(abi.Geometry), C.sizeof(abi.Params), C.sizeof(abi.StateDesc), C.sizeof(abi.ActionDesc),
+            abi.Params.n0.offset, abi.StateDesc.effective_zero.offset, abi.StateDesc.bc.offset,
+            abi.ActionDesc.cross_sections.offset]
+    assert got == want
 
 
 def test_version_and_pure_host_entry_points():
