@@ -21,6 +21,7 @@ BC_BOGUS, BC_REFLECT_ODD, BC_INT_DIR, BC_REFLECT_EVEN, BC_FOEXTRAP, BC_EXT_DIR, 
 
 ACTION = {"CTU": 0, "plasma5": 1, "Lorentz": 2, "collisions_rambo": 3}
 SOLVER = {"explicit": 0, "implicit": 1}
+VISCOSITY = {"Sutherland": 1, "PowerLaw": 2, "UserDefined": 3}
 TIME_INTEGRATOR = {"euler": 0, "RK2": 1, "strang": 2}
 FP_STRICT, FP_FAST = 0, 1
 
@@ -61,6 +62,12 @@ class StateDesc(C.Structure):
         ("div_transport", C.c_double),
         ("div_damping", C.c_double),
         ("effective_zero", C.c_double),
+        ("viscosity", C.c_int),
+        ("visc_mu0", C.c_double),
+        ("visc_T0", C.c_double),
+        ("visc_S", C.c_double),
+        ("visc_n", C.c_double),
+        ("visc_Pr", C.c_double),
         ("bc", ((C.c_int * 2) * MAX_DIM) * MAX_COMP),
     ]
 

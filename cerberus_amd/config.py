@@ -35,8 +35,12 @@ def update_ref(cfg):
     if T_ref > 0 and c > 0:
         raise ValueError("ref_temp and lightspeed both set, only set one")   # :398
     if T_ref > 0:
-        c = c_ref / math.sqrt(kB * T_ref / m_ref)     # :400-404
-    elif not c > 0:
+        u_ref = math.sqrt(kB * T_ref / m_ref)         # :400-404
+        c = c_ref / u_ref
+    elif c > 0:
+        u_ref = c_ref / c                              # :405-409
+        T_ref = ((c_ref * c_ref) / (c * c)) * (m_ref / kB)
+    else:
         raise ValueError("Either ref_temp or lightspeed need to be set, only set one")
     Larmor, Debye, beta, skin = g["Larmor"], g["Debye"], g["beta"], g["skin_depth"]
     if Larmor > 0 and Debye > 0:                    # :420-421, case 1
@@ -47,7 +51,8 @@ def update_ref(cfg):
         Larmor = math.sqrt(beta / 2.0) * skin
     else:
         raise ValueError("plasma parameters not set")
-    return dict(lightspeed=c, Larmor=Larmor, Debye=Debye, beta=beta, skin_depth=skin, n0=n0, x_ref=x_ref)
+    return dict(lightspeed=c, Larmor=Larmor, Debye=Debye, beta=beta, skin_depth=skin, n0=n0, x_ref=x_ref,
+                rho_ref=rho_ref, u_ref=u_ref, T_ref=T_ref)
 
 
 class Problem:
@@ -118,6 +123,27 @@ class Problem:
                     if sd["shock_detector"].get("name") != "pressure_jump_detector":
                         raise ValueError("unknown shock detector")
                     d.shock_threshold = float(sd["shock_detector"]["threshold"])
+                visc = sd.get("viscosity")
+                if visc:                                   # MFP_hydro.cpp:86-111, MFP_hydro_viscous.cpp
+                    if visc["type"] not in abi.VISCOSITY:
+                        raise ValueError(f"Invalid viscosity option '{visc['type']}'")
+                    d.viscosity = abi.VISCOSITY[visc["type"]]
+                    r = self.ref
+                    d.visc_Pr = float(visc["Pr"])
+                    if visc["type"] == "UserDefined":
+                        d.visc_mu0 = float(visc["mu0"])            # :257-258: taken as given
+                        ok = d.visc_mu0 > 0
+                    else:
+                        d.visc_mu0 = float(visc["mu0"]) / (r["rho_ref"] * r["x_ref"] * r["u_ref"])
+                        d.visc_T0 = float(visc["T0"]) / r["T_ref"]
+                        if visc["type"] == "Sutherland":
+                            d.visc_S = float(visc["S"]) / r["T_ref"]
+                            ok = d.visc_mu0 > 0 and d.visc_T0 > 0 and d.visc_S > 0
+                        else:
+                            d.visc_n = float(visc["n"])
+                            ok = d.visc_mu0 > 0 and d.visc_T0 > 0 and d.visc_n > 0
+                    if not ok:
+                        raise ValueError(f"{visc['type']} input coefficients non-physical")
                 table = bc.hydro_bc(sd.get("bc", {}), self.dim, self.periodic)
             elif sd["type"] == "field":
                 d.kind = abi.STATE_FIELD

@@ -380,6 +380,8 @@ int ctu_staged(cmfp_context* c, const cmfp_action_desc& A, double dt) {
             for (int d = 0; d < g.dim; ++d)                                          // :349
                 c->L->fluxes(g, s.sp, d, s.rlo[d], s.rhi[d], s.flux[d], do_ctu, c->stream);
         }
+        if (s.sp.kind == CMFP_STATE_HYDRO && s.sp.visc.kind)                         // :370-380
+            for (int d = 0; d < g.dim; ++d) c->L->viscous(g, s.sp, d, s.U, s.flux[d], c->stream);
         c->L->divergence(g, s.sp.nc, fl, s.dU, dt, c->stream);                       // :504
     }
     return CMFP_OK;
@@ -540,6 +542,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         if (A.kind == CMFP_ACTION_CTU)
             for (int i = 0; i < A.n_states; ++i) {
                 const StatePhys& sp = c->states[A.states[i]].sp;
+                if (sp.kind == CMFP_STATE_HYDRO && sp.visc.kind) return 0;  // viscous fluxes: stage-by-stage kernels only
                 if (c->fused != 2 && c->L->ctu_fused(c->g, sp, nullptr, nullptr, A.corner_transport, dt, c->touches, nullptr,
                                                      nullptr, 0, c->stream)) {
                     tiled[A.states[i]] = 1;
@@ -697,6 +700,7 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     for (int s = 0; s < n_states; ++s) {
         int n = recon_num_grow(states[s].reconstruction);
         if (n < 0) return fail(c, CMFP_ERR_INVALID, "unknown reconstruction");
+        if (states[s].kind == CMFP_STATE_HYDRO && states[s].viscosity) n = std::max(n, 2);  // MFP_hydro.cpp:108-110
         ng = std::max(ng, n);
     }
     Geo& g = c->g;
@@ -730,6 +734,15 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
         sp.recon = states[s].reconstruction;
         sp.flux = states[s].flux;
         sp.ng = recon_num_grow(sp.recon);
+        if (sp.kind == CMFP_STATE_HYDRO && states[s].viscosity) {
+            if (states[s].viscosity < CMFP_VISC_SUTHERLAND || states[s].viscosity > CMFP_VISC_USER)
+                return fail(c, CMFP_ERR_INVALID, "Invalid viscosity option");
+            if (geom->dim > 2)
+                return fail(c, CMFP_ERR_INVALID, "viscous fluxes: 1-D and 2-D only (the reference's 3-D branch does not compile)");
+            sp.ng = std::max(sp.ng, 2);
+            sp.visc = ViscP{states[s].viscosity, states[s].visc_mu0, states[s].visc_T0, states[s].visc_S, states[s].visc_n,
+                            states[s].visc_Pr};
+        }
         if (sp.kind == CMFP_STATE_HYDRO) {
             sp.nc = sp.nq = 5;
             if (sp.flux != CMFP_FLUX_HLLC && sp.flux != CMFP_FLUX_HLLE && sp.flux != CMFP_FLUX_HYBRID_HLL)
@@ -776,9 +789,9 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     }
     HIPCHK(c, hipMalloc((void**)&c->d_err, sizeof(int)));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
-    HIPCHK(c, hipMalloc((void**)&c->d_red, sizeof(unsigned long long) * (n_states + n_actions + 1)));
-    HIPCHK(c, hipMalloc((void**)&c->d_part, sizeof(double) * (size_t)(n_states + n_actions + 1) * CMFP_RED_BLOCKS));
-    c->red_valid.assign(n_states + n_actions + 1, 0);
+    HIPCHK(c, hipMalloc((void**)&c->d_red, sizeof(unsigned long long) * (2 * n_states + n_actions + 1)));
+    HIPCHK(c, hipMalloc((void**)&c->d_part, sizeof(double) * (size_t)(2 * n_states + n_actions + 1) * CMFP_RED_BLOCKS));
+    c->red_valid.assign(2 * n_states + n_actions + 1, 0);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CMFP_OK;
 }
@@ -926,12 +939,28 @@ static int launch_state_dt(cmfp_context* c, int s, int w) {
                     c->stream);
     return CMFP_OK;
 }
-static double state_dt_from(const cmfp_context* c, int s, double max_speed) {
+static bool state_viscous(const cmfp_context* c, int s) {
+    return c->states[s].sp.kind == CMFP_STATE_HYDRO && c->states[s].sp.visc.kind != 0;
+}
+// word of the viscous stability reduction of state s
+static int visc_word(const cmfp_context* c, int s) { return (int)(c->states.size() + c->actions.size()) + s; }
+static int launch_visc_dt(cmfp_context* c, int s) {
+    const int w = visc_word(c, s);
+    c->L->visc_stability(c->g, c->states[s].sp, c->states[s].new_data, c->d_part + (size_t)w * CMFP_RED_BLOCKS, c->d_red + w,
+                         c->stream);
+    return CMFP_OK;
+}
+static double state_dt_from(const cmfp_context* c, int s, double max_speed, double visc_max) {
     const StateRT& st = c->states[s];
     const Geo& g = c->g;
     const double sp = st.sp.kind == CMFP_STATE_HYDRO ? max_speed : st.sp.fp.fastest;
     double dt = g.dx[0] / sp;  // MFP_eulerian.cpp:302-303, MFP_field.cpp:63-64
     for (int i = 1; i < g.dim; ++i) dt = std::min(dt, g.dx[i] / sp);
+    if (state_viscous(c, s)) {  // HydroState::get_allowed_time_step MFP_hydro.cpp:726-736, MFP_hydro_viscous.cpp:88-96
+        double min_dt = std::numeric_limits<double>::max();
+        for (int d = 0; d < g.dim; ++d) min_dt = std::min(min_dt, g.dx[d] * g.dx[d] / visc_max);
+        dt = std::min(dt, min_dt);
+    }
     return dt;
 }
 static int launch_action_dt(cmfp_context* c, int a, int w) {
@@ -957,14 +986,15 @@ int cmfp_state_get_allowed_time_step(cmfp_context* c, int s, double* dt) {
     int r;
     if ((r = check_ctx(c))) return r;
     if (s < 0 || s >= (int)c->states.size() || !dt) return fail(c, CMFP_ERR_INVALID, "bad state index / pointer");
-    const int nw = (int)(c->states.size() + c->actions.size());
+    const int nw = (int)(2 * c->states.size() + c->actions.size());
     std::vector<unsigned long long> h(nw, 0);
     if (c->states[s].sp.kind == CMFP_STATE_HYDRO) {
         if (!c->red_valid[s] && (r = launch_state_dt(c, s, s))) return r;
         c->red_valid[s] = 1;
+        if (state_viscous(c, s) && (r = launch_visc_dt(c, s))) return r;
         if ((r = reduce_words(c, h))) return r;
     }
-    *dt = state_dt_from(c, s, as_double(h[s]));
+    *dt = state_dt_from(c, s, as_double(h[s]), as_double(h[visc_word(c, s)]));
     return CMFP_OK;
 }
 int cmfp_action_get_allowed_time_step(cmfp_context* c, int a, double* dt) {
@@ -990,12 +1020,14 @@ int cmfp_est_time_step(cmfp_context* c, double* out) {
     if ((r = check_ctx(c))) return r;
     if (!out) return fail(c, CMFP_ERR_INVALID, "null pointer");
     const int ns = (int)c->states.size(), na = (int)c->actions.size();
-    std::vector<unsigned long long> h(ns + na, 0);
-    for (int s = 0; s < ns; ++s)
+    std::vector<unsigned long long> h(2 * ns + na, 0);
+    for (int s = 0; s < ns; ++s) {
         if (c->states[s].sp.kind == CMFP_STATE_HYDRO && !c->red_valid[s]) {
             if ((r = launch_state_dt(c, s, s))) return r;
             c->red_valid[s] = 1;
         }
+        if (state_viscous(c, s) && (r = launch_visc_dt(c, s))) return r;
+    }
     for (int a = 0; a < na; ++a)
         if (action_limits_dt(c->actions[a]) && !c->red_valid[ns + a]) {
             if ((r = launch_action_dt(c, a, ns + a))) return r;
@@ -1003,7 +1035,7 @@ int cmfp_est_time_step(cmfp_context* c, double* out) {
         }
     if ((r = reduce_words(c, h))) return r;
     double estdt = std::numeric_limits<double>::max();
-    for (int s = 0; s < ns; ++s) estdt = std::min(estdt, state_dt_from(c, s, as_double(h[s])));
+    for (int s = 0; s < ns; ++s) estdt = std::min(estdt, state_dt_from(c, s, as_double(h[s]), as_double(h[visc_word(c, s)])));
     for (int a = 0; a < na; ++a)
         if (action_limits_dt(c->actions[a])) estdt = std::min(estdt, action_dt_from(c, a, as_double(h[ns + a])));
     estdt *= c->params.cfl;

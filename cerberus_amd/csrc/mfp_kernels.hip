@@ -748,6 +748,109 @@ __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs 
     }
 }
 
+// ------------------------------------------------------------------ viscous hydro fluxes
+// Cell quantities the viscous terms need, from the conserved data with the arithmetic of
+// ThermallyPerfectGas::cons2prim (so u, v, w, T equal the reference's primitive array), and
+// HydroViscous::get_coeffs (MFP_hydro_viscous.cpp:145-160, 207-220, 266-279).
+struct ViscCell {
+    double u, v, w, T, mu, kappa, rho;
+};
+__device__ __forceinline__ double visc_mu(const ViscP& V, double T) {
+    if (V.kind == 1) {  // CMFP_VISC_SUTHERLAND
+        const double T_ = T / V.T0;
+        return V.mu0 * T_ * sqrt(T_) * (V.T0 + V.S) / (T + V.S);
+    }
+    if (V.kind == 2) return  /* CMFP_VISC_POWERLAW */ V.mu0 * pow(T / V.T0, V.n);
+    return V.mu0;
+}
+__device__ __forceinline__ ViscCell visc_cell(const GasP& G, const ViscP& V, const double* __restrict__ U, long c, long sc) {
+    ViscCell q;
+    const double rho = U[c], mx = U[c + sc], my = U[c + 2 * sc], mz = U[c + 3 * sc], ed = U[c + 4 * sc];
+    const double rhoinv = 1 / rho;
+    q.rho = rho;
+    q.u = mx * rhoinv;
+    q.v = my * rhoinv;
+    q.w = mz * rhoinv;
+    const double ke = 0.5 * rho * (q.u * q.u + q.v * q.v + q.w * q.w);
+    const double p = (ed - ke) * (G.gamma - 1);
+    q.T = p * rhoinv * G.mass;
+    const double cp = G.gamma / (G.mass * (G.gamma - 1));  // MFP_thermally_perfect_gas.cpp:127
+    q.mu = visc_mu(V, q.T);
+    q.kappa = q.mu * cp / V.Pr;
+    return q;
+}
+
+// HydroState::calc_viscous_fluxes MFP_hydro.cpp:1085-1271, one thread per face of direction D.
+// `two_thirds = 2 / 3` is integer division in the reference (:1123): the divergence term is absent.
+template <int D>
+__global__ void k_viscous(Geo g, IBox faces, GasP G, ViscP V, const double* __restrict__ U, double* __restrict__ flux) {
+    int i, j, k;
+    if (!decode(faces, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long sc = g.sc;
+    const long c = g.at(i, j, k);
+    const long sx = 1, sy = g.sj;
+    const double dxinv0 = 1 / g.dx[0], dxinv1 = 1 / g.dx[1];
+    const double two_thirds = 2 / 3;
+    const long cm = c - (D == 0 ? sx : sy);
+    const ViscCell a = visc_cell(G, V, U, c, sc), b = visc_cell(G, V, U, cm, sc);
+    double dudz = 0, dwdz = 0, dvdz = 0;
+    if (D == 0) {
+        const double dTdx = (a.T - b.T) * dxinv0;
+        const double dudx = (a.u - b.u) * dxinv0;
+        const double dvdx = (a.v - b.v) * dxinv0;
+        const double dwdx = (a.w - b.w) * dxinv0;
+        double dudy = 0, dvdy = 0;
+        if (g.dim >= 2) {
+            const ViscCell pa = visc_cell(G, V, U, c + sy, sc), pb = visc_cell(G, V, U, cm + sy, sc);
+            const ViscCell ma = visc_cell(G, V, U, c - sy, sc), mb = visc_cell(G, V, U, cm - sy, sc);
+            dudy = (pa.u + pb.u - ma.u - mb.u) * (0.25 * dxinv1);
+            dvdy = (pa.v + pb.v - ma.v - mb.v) * (0.25 * dxinv1);
+        }
+        const double divu = dudx + dvdy + dwdz;
+        const double muf = 0.5 * (a.mu + b.mu);
+        const double tauxx = muf * (2 * dudx - two_thirds * divu);
+        const double tauxy = muf * (dudy + dvdx);
+        const double tauxz = muf * (dudz + dwdx);
+        flux[c + 1 * sc] -= tauxx;
+        flux[c + 2 * sc] -= tauxy;
+        flux[c + 3 * sc] -= tauxz;
+        flux[c + 4 * sc] -= 0.5 * ((a.u + b.u) * tauxx + (a.v + b.v) * tauxy + (a.w + b.w) * tauxz + (a.kappa + b.kappa) * dTdx);
+    } else {
+        const double dTdy = (a.T - b.T) * dxinv1;
+        const double dudy = (a.u - b.u) * dxinv1;
+        const double dvdy = (a.v - b.v) * dxinv1;
+        const double dwdy = (a.w - b.w) * dxinv1;
+        const ViscCell pa = visc_cell(G, V, U, c + sx, sc), pb = visc_cell(G, V, U, cm + sx, sc);
+        const ViscCell ma = visc_cell(G, V, U, c - sx, sc), mb = visc_cell(G, V, U, cm - sx, sc);
+        const double dudx = (pa.u + pb.u - ma.u - mb.u) * (0.25 * dxinv0);
+        const double dvdx = (pa.v + pb.v - ma.v - mb.v) * (0.25 * dxinv0);
+        const double divu = dudx + dvdy + dwdz;
+        const double muf = 0.5 * (a.mu + b.mu);
+        const double tauyy = muf * (2 * dvdy - two_thirds * divu);
+        const double tauxy = muf * (dudy + dvdx);
+        const double tauyz = muf * (dwdy + dvdz);
+        flux[c + 1 * sc] -= tauxy;
+        flux[c + 2 * sc] -= tauyy;
+        flux[c + 3 * sc] -= tauyz;
+        flux[c + 4 * sc] -= 0.5 * ((a.u + b.u) * tauxy + (a.v + b.v) * tauyy + (a.w + b.w) * tauyz + (a.kappa + b.kappa) * dTdy);
+    }
+}
+
+// HydroViscous::get_min_dt MFP_hydro_viscous.cpp:34-97, cell loop: max of calc_stability_condition
+// (:162-176, 222-236, 281-292), starting from 0
+__global__ void k_visc_stability(Geo g, IBox box, GasP G, ViscP V, const double* __restrict__ U, double* part) {
+    const long npts = box.npts();
+    double m = 0.0;
+    for (long t = (long)blockIdx.x * TPB + threadIdx.x; t < npts; t += (long)gridDim.x * TPB) {
+        int i, j, k;
+        decode(box, t, i, j, k);
+        const ViscCell q = visc_cell(G, V, U, g.at(i, j, k), g.sc);
+        const double s = (4 * q.mu * G.gamma / (V.Pr * q.rho));
+        m = (m < s) ? s : m;
+    }
+    block_reduce_store<true>(m, part);
+}
+
 // EulerianState::get_allowed_time_step MFP_eulerian.cpp:255-300: max over valid
 // cells and over d < DIM of get_speed_from_cons.
 __global__ void k_max_speed(Geo g, IBox box, HydroParams hp, const double* __restrict__ U, double* part) {
@@ -1071,6 +1174,21 @@ static void l_max_speed(const Geo& g, const StatePhys& sp, const double* U, doub
     hipLaunchKernelGGL(k_max_speed, dim3(nb), dim3(TPB), 0, st, g, b, sp.hp, U, part);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, part, (int)nb, 1, out);
 }
+static void l_viscous(const Geo& g, const StatePhys& sp, int d, const double* U, double* flux, hipStream_t st) {
+    IBox f = valid_box(g);
+    f.hi[d] += 1;  // faces lo.d .. hi.d + 1 of the box (MFP_hydro.cpp:1131,1208)
+    if (d == 0)
+        LAUNCH((k_viscous<0>), f.npts(), st, g, f, sp.hp.gas, sp.visc, U, flux);
+    else
+        LAUNCH((k_viscous<1>), f.npts(), st, g, f, sp.hp.gas, sp.visc, U, flux);
+}
+static void l_visc_stability(const Geo& g, const StatePhys& sp, const double* U, double* part, unsigned long long* out,
+                             hipStream_t st) {
+    IBox b = valid_box(g);
+    const unsigned nb = red_blocks(b.npts());
+    hipLaunchKernelGGL(k_visc_stability, dim3(nb), dim3(TPB), 0, st, g, b, sp.hp.gas, sp.visc, U, part);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, part, (int)nb, 1, out);
+}
 static void l_plasma_dt(const Geo& g, const SourceArgs& a, double* part, unsigned long long* out, hipStream_t st) {
     IBox b = valid_box(g);
     const unsigned nb = red_blocks(b.npts());
@@ -1160,7 +1278,7 @@ static void l_reduce_final(const double* part, int n, int is_max, unsigned long 
 const Launchers* launchers() {
     static const Launchers L = {l_prim,      l_recon,         l_face_bc,        l_fluxes,          l_correct,
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
-                                l_source,    l_max_speed,     l_plasma_dt,      l_fill_dim,        l_pack,
+                                l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_fill_dim,        l_pack,
                                 ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
                                 l_leaf_prim2cons, l_reduce_final};
     return &L;

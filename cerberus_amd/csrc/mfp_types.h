@@ -40,6 +40,12 @@ struct IBox {
     }
 };
 
+// HydroViscous (hydro/viscous/MFP_hydro_viscous.cpp): kind = cmfp_viscosity, non-dimensional coefficients
+struct ViscP {
+    int kind;
+    double mu0, T0, S, n, Pr;
+};
+
 struct StatePhys {
     int kind;   // cmfp_state_kind
     int recon;  // cmfp_recon
@@ -48,6 +54,7 @@ struct StatePhys {
     int nq;     // primitive comps carried (5 / 10)
     int ng;     // Reconstruction::num_grow of this state (<= the context's common ghost width)
     HydroParams hp;
+    ViscP visc;
     FieldParams fp;
     int bc[10][3][2];
 };
@@ -121,6 +128,10 @@ struct Launchers {
     // dt limits: result combined into *out (bits of a positive double) with atomics
     void (*max_speed)(const Geo&, const StatePhys&, const double* U, double* part, unsigned long long* out, hipStream_t);
     void (*plasma_dt)(const Geo&, const SourceArgs&, double* part, unsigned long long* out, hipStream_t);
+    // HydroState::calc_viscous_fluxes for direction d: flux -= viscous stresses (cell data from U)
+    void (*viscous)(const Geo&, const StatePhys&, int d, const double* U, double* flux, hipStream_t);
+    // HydroViscous::get_min_dt cell loop: max over valid cells of calc_stability_condition
+    void (*visc_stability)(const Geo&, const StatePhys&, const double* U, double* part, unsigned long long* out, hipStream_t);
     // ghosts
     void (*fill_dim)(const Geo&, int nc, int ngs, double* A, int d, int side, FillRules, hipStream_t);
     void (*pack)(const Geo&, int nc, int ngs, double* A, int d, int side, double* buf, int unpack, hipStream_t);

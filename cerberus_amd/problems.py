@@ -157,6 +157,39 @@ def collisions_relaxation(n=4, neutral=False):
     }
 
 
+def viscous_vortex_2d(n=384, recon="O6"):
+    """Exec/testing/Viscous-Vortex (problem_definition.lua, vortex.inputs): a decaying Lamb-Oseen vortex
+    (Munoz et al. 2013) in a viscous gas, PowerLaw viscosity with mu0 = 0.08, O6 + HLLC + CTU, `euler`
+    integrator, periodic [-20, 20]^2.  The reference refines [-8, 8]^2 by 4 over 96^2 (dx = 0.104); n = 384
+    is that resolution everywhere.  Its check.py accepts |v - v_theta| / v_theta <= 1 % for r <= 8 at t = 20."""
+    from scipy.special import expi
+    kB = 1.38064852e-23
+    G, t0, mu0, rho0, p0 = 1.0, 10.0, 0.08, 1.0, 1.00548676
+    nu = mu0 / rho0
+
+    def P(r):   # pressure_definition.py
+        return p0 - (G ** 2 * rho0 * ((-1 + np.exp(r ** 2 / (4. * t0 * nu))) ** 2 / (2. * np.exp(r ** 2 / (2. * t0 * nu)) * r ** 2)
+                                      + (expi(-r ** 2 / (2. * t0 * nu)) - expi(-r ** 2 / (4. * t0 * nu))) / (4. * t0 * nu))) / (4. * np.pi ** 2)
+    r_tab = np.linspace(1e-6, 30, 1000)      # the table the reference interpolates linearly (pressure.lua)
+    p_tab = P(r_tab)
+    radius = lambda d: np.sqrt(d["x"] ** 2 + d["y"] ** 2)
+    vt = lambda r: G / (2 * math.pi * r) * (1 - np.exp(-r ** 2 / (4 * nu * t0)))
+    return {
+        "dim": 2, "n_cell": [n, n], "prob_lo": [-20.0, -20.0], "prob_hi": [20.0, 20.0], "is_periodic": [1, 1],
+        "cfl": 0.5, "time_integration_scheme": "euler", "ref_temp": 1 / kB,
+        "states": {
+            "air": {"type": "hydro", "gas": {"type": "thermally_perfect", "mass": 1.0, "charge": 0.0, "gamma": 5 / 3},
+                    "reconstruction": recon, "flux": "HLLC",
+                    "viscosity": {"Pr": 0.71, "mu0": mu0, "T0": 1 / kB, "n": 1, "type": "PowerLaw"},
+                    "value": {"rho": 1.0,
+                              "x_vel": lambda d: vt(radius(d)) * d["y"] / radius(d),
+                              "y_vel": lambda d: -vt(radius(d)) * d["x"] / radius(d),
+                              "p": lambda d: np.interp(radius(d), r_tab, p_tab)}},
+        },
+        "actions": {"hydro_fluxes": {"type": "CTU", "corner_transport": True, "states": ["air"]}},
+    }
+
+
 def gem_reconnection_2d(nx=8192, ny=None):
     """GEM challenge (Birn et al. 2001) two-fluid set-up, SURVEY.md §8(d) config 4."""
     ny = nx // 2 if ny is None else ny
@@ -267,4 +300,5 @@ WORKLOADS = {
     "gem_2d": gem_reconnection_2d,
     "rmi_3d": richtmyer_meshkov_3d,
     "collisions": collisions_relaxation,
+    "viscous_vortex": viscous_vortex_2d,
 }

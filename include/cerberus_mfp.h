@@ -83,6 +83,9 @@ typedef enum {
 
 typedef enum { CMFP_SOLVER_EXPLICIT = 0, CMFP_SOLVER_IMPLICIT = 1 } cmfp_source_solver;
 
+/* viscosity.type: "Sutherland", "PowerLaw", "UserDefined" (MFP_hydro_viscous.cpp:117,183,243) */
+typedef enum { CMFP_VISC_NONE = 0, CMFP_VISC_SUTHERLAND = 1, CMFP_VISC_POWERLAW = 2, CMFP_VISC_USER = 3 } cmfp_viscosity;
+
 /* time_integration_scheme (MFP_config.cpp:71-87). */
 typedef enum { CMFP_TI_EULER = 0, CMFP_TI_RK2 = 1, CMFP_TI_STRANG = 2 } cmfp_time_integrator;
 
@@ -131,6 +134,11 @@ typedef struct {
     double div_transport;   /* field: c_h / c                                  */
     double div_damping;     /* field                                           */
     double effective_zero;  /* states.<name>.effective_zero (MFP_eulerian.cpp:62), default 1e-14 */
+    /* hydro: states.<name>.viscosity (hydro/viscous/MFP_hydro_viscous.cpp), coefficients already
+     * non-dimensionalised as the reference's constructors do (:136-139, :198-200):
+     * mu0 / (rho_ref x_ref u_ref), T0 / T_ref, S / T_ref.  2-D and 1-D blocks only. */
+    int viscosity;          /* cmfp_viscosity */
+    double visc_mu0, visc_T0, visc_S, visc_n, visc_Pr;
     /* BCRec per conserved component: bc[comp][dim][0=lo,1=hi] (cmfp_bc).
      * hydro uses comps 0..4, field 0..9. */
     int bc[CMFP_MAX_COMP][CMFP_MAX_DIM][2];

@@ -635,6 +635,127 @@ struct StateDef {
     bool hydro() const { return desc.kind == CMFP_STATE_HYDRO; }
 };
 
+// HydroViscous family, hydro/viscous/MFP_hydro_viscous.cpp: get_coeffs (:145-160 Sutherland,
+// :207-220 PowerLaw, :266-279 UserDefined) and calc_stability_condition (:162-176, :222-236, :281-292)
+static void visc_coeffs(const StateDef& S, const Real* Q, Real& T, Real& mu, Real& kappa) {
+    const cmfp_state_desc& d = S.desc;
+    T = Q[Temp];
+    Real cp = S.gas.cp();
+    if (d.viscosity == CMFP_VISC_SUTHERLAND) {
+        Real T_ = T / d.visc_T0;
+        mu = d.visc_mu0 * T_ * sqrt(T_) * (d.visc_T0 + d.visc_S) / (T + d.visc_S);
+    } else if (d.viscosity == CMFP_VISC_POWERLAW) {
+        mu = d.visc_mu0 * pow(T / d.visc_T0, d.visc_n);
+    } else {
+        mu = d.visc_mu0;
+    }
+    kappa = mu * cp / d.visc_Pr;
+}
+static Real visc_stability(const StateDef& S, const Real* U) {
+    const cmfp_state_desc& d = S.desc;
+    Real Q[HP_NUM];
+    // get_temperature_from_cons (MFP_thermally_perfect_gas.cpp:271-292): the arithmetic of cons2prim
+    Real rho = U[Density];
+    Real rhoinv = 1 / rho;
+    Real u = U[Xmom] * rhoinv, v = U[Ymom] * rhoinv, w = U[Zmom] * rhoinv;
+    Real ke = 0.5 * rho * (u * u + v * v + w * w);
+    Real p = (U[Eden] - ke) * (S.gas.gamma - 1);
+    Real T = p * rhoinv * S.gas.mass;
+    (void)Q;
+    Real mu;
+    if (d.viscosity == CMFP_VISC_SUTHERLAND) {
+        const Real T_ = T / d.visc_T0;
+        mu = d.visc_mu0 * T_ * sqrt(T_) * (d.visc_T0 + d.visc_S) / (T + d.visc_S);
+    } else if (d.viscosity == CMFP_VISC_POWERLAW) {
+        mu = d.visc_mu0 * pow(T / d.visc_T0, d.visc_n);
+    } else {
+        mu = d.visc_mu0;
+    }
+    return (4 * mu * S.gas.gamma / (d.visc_Pr * rho));
+}
+
+// HydroState::calc_viscous_fluxes MFP_hydro.cpp:1085-1329 (regular cells; 1-D and 2-D: the 3-D
+// branch of the reference names undeclared variables).  `two_thirds = 2 / 3` is integer division in
+// the reference (:1123), i.e. 0: the divergence term is absent.  Reproduced.
+static void calc_viscous_fluxes(const StateDef& S, int DIM, const Box& box, Fab* fluxes, const Fab& prim, const Real* dx) {
+    Real dxinv[3];
+    for (int d = 0; d < DIM; ++d) dxinv[d] = 1 / dx[d];
+    const Real two_thirds = 2 / 3;
+    auto coef = [&](int i, int j, int k, Real& T, Real& mu, Real& kappa) {
+        Real Q[HP_NUM];
+        for (int n = 0; n < HP_NUM; ++n) Q[n] = prim(i, j, k, n);
+        visc_coeffs(S, Q, T, mu, kappa);
+    };
+    Real dudx = 0, dudy = 0, dudz = 0, dvdx = 0, dvdy = 0, dwdx = 0, dwdz = 0, divu = 0;
+    Real tauxx, tauxy, tauxz, dTdx, muf;
+    Fab& fluxX = fluxes[0];
+    for (int k = box.lo[2]; k <= box.hi[2]; ++k)
+        for (int j = box.lo[1]; j <= box.hi[1]; ++j)
+            for (int i = box.lo[0]; i <= box.hi[0] + 1; ++i) {
+                Real T1, mu1, ka1, T0, mu0, ka0;
+                coef(i, j, k, T1, mu1, ka1);
+                coef(i - 1, j, k, T0, mu0, ka0);
+                dTdx = (T1 - T0) * dxinv[0];
+                dudx = (prim(i, j, k, Xvel) - prim(i - 1, j, k, Xvel)) * dxinv[0];
+                dvdx = (prim(i, j, k, Yvel) - prim(i - 1, j, k, Yvel)) * dxinv[0];
+                dwdx = (prim(i, j, k, Zvel) - prim(i - 1, j, k, Zvel)) * dxinv[0];
+                if (DIM >= 2) {
+                    dudy = (prim(i, j + 1, k, Xvel) + prim(i - 1, j + 1, k, Xvel) - prim(i, j - 1, k, Xvel) -
+                            prim(i - 1, j - 1, k, Xvel)) *
+                           (0.25 * dxinv[1]);
+                    dvdy = (prim(i, j + 1, k, Yvel) + prim(i - 1, j + 1, k, Yvel) - prim(i, j - 1, k, Yvel) -
+                            prim(i - 1, j - 1, k, Yvel)) *
+                           (0.25 * dxinv[1]);
+                }
+                divu = dudx + dvdy + dwdz;
+                muf = 0.5 * (mu1 + mu0);
+                tauxx = muf * (2 * dudx - two_thirds * divu);
+                tauxy = muf * (dudy + dvdx);
+                tauxz = muf * (dudz + dwdx);
+                fluxX(i, j, k, Xmom) -= tauxx;
+                fluxX(i, j, k, Ymom) -= tauxy;
+                fluxX(i, j, k, Zmom) -= tauxz;
+                fluxX(i, j, k, Eden) -= 0.5 * ((prim(i, j, k, Xvel) + prim(i - 1, j, k, Xvel)) * tauxx +
+                                               (prim(i, j, k, Yvel) + prim(i - 1, j, k, Yvel)) * tauxy +
+                                               (prim(i, j, k, Zvel) + prim(i - 1, j, k, Zvel)) * tauxz +
+                                               (ka1 + ka0) * dTdx);
+            }
+    if (DIM >= 2) {
+        Real tauyy, tauyz, dTdy;
+        Real dvdz = 0, dwdy = 0;
+        Fab& fluxY = fluxes[1];
+        for (int k = box.lo[2]; k <= box.hi[2]; ++k)
+            for (int j = box.lo[1]; j <= box.hi[1] + 1; ++j)
+                for (int i = box.lo[0]; i <= box.hi[0]; ++i) {
+                    Real T1, mu1, ka1, T0, mu0, ka0;
+                    coef(i, j, k, T1, mu1, ka1);
+                    coef(i, j - 1, k, T0, mu0, ka0);
+                    dTdy = (T1 - T0) * dxinv[1];
+                    dudy = (prim(i, j, k, Xvel) - prim(i, j - 1, k, Xvel)) * dxinv[1];
+                    dvdy = (prim(i, j, k, Yvel) - prim(i, j - 1, k, Yvel)) * dxinv[1];
+                    dwdy = (prim(i, j, k, Zvel) - prim(i, j - 1, k, Zvel)) * dxinv[1];
+                    dudx = (prim(i + 1, j, k, Xvel) + prim(i + 1, j - 1, k, Xvel) - prim(i - 1, j, k, Xvel) -
+                            prim(i - 1, j - 1, k, Xvel)) *
+                           (0.25 * dxinv[0]);
+                    dvdx = (prim(i + 1, j, k, Yvel) + prim(i + 1, j - 1, k, Yvel) - prim(i - 1, j, k, Yvel) -
+                            prim(i - 1, j - 1, k, Yvel)) *
+                           (0.25 * dxinv[0]);
+                    divu = dudx + dvdy + dwdz;
+                    muf = 0.5 * (mu1 + mu0);
+                    tauyy = muf * (2 * dvdy - two_thirds * divu);
+                    tauxy = muf * (dudy + dvdx);
+                    tauyz = muf * (dwdy + dvdz);
+                    fluxY(i, j, k, Xmom) -= tauxy;
+                    fluxY(i, j, k, Ymom) -= tauyy;
+                    fluxY(i, j, k, Zmom) -= tauyz;
+                    fluxY(i, j, k, Eden) -= 0.5 * ((prim(i, j, k, Xvel) + prim(i, j - 1, k, Xvel)) * tauxy +
+                                                   (prim(i, j, k, Yvel) + prim(i, j - 1, k, Yvel)) * tauyy +
+                                                   (prim(i, j, k, Zvel) + prim(i, j - 1, k, Zvel)) * tauyz +
+                                                   (ka1 + ka0) * dTdy);
+                }
+    }
+}
+
 struct Sim;
 
 // per-state virtuals of EulerianState
@@ -1277,6 +1398,7 @@ struct Sim {
                     update_face_prim(S, G, box, R_lo, R_hi, true);
                     calc_fluxes(S, DIM, P.lightspeed, R_lo, R_hi, fluxes);
                 }
+                if (S.hydro() && S.desc.viscosity) calc_viscous_fluxes(S, DIM, box, fluxes, prim, G.dx);  // MFP_CTU_hydro.cpp:370-380
                 calc_divergence(DIM, box, fluxes, update[s].dU[b], G.dx, dt);
             }
         }
@@ -1735,6 +1857,24 @@ struct Sim {
         }
         Real dt = G.dx[0] / max_speed;
         for (int i = 1; i < DIM; ++i) dt = std::min(dt, G.dx[i] / max_speed);
+        if (S.desc.viscosity) {
+            // HydroState::get_allowed_time_step MFP_hydro.cpp:726-736 with HydroViscous::get_min_dt
+            // (MFP_hydro_viscous.cpp:34-97): max over cells starts from 0
+            Real vmax = 0;
+            for (size_t b = 0; b < boxes.size(); ++b) {
+                const Box& bx = boxes[b];
+                const Fab& data = new_data[s][b];
+                for (int k = bx.lo[2]; k <= bx.hi[2]; ++k)
+                    for (int j = bx.lo[1]; j <= bx.hi[1]; ++j)
+                        for (int i = bx.lo[0]; i <= bx.hi[0]; ++i) {
+                            for (int n = 0; n < S.n_cons; ++n) U[n] = data(i, j, k, n);
+                            vmax = std::max(vmax, visc_stability(S, U));
+                        }
+            }
+            Real min_dt = std::numeric_limits<Real>::max();
+            for (int d = 0; d < DIM; ++d) min_dt = std::min(min_dt, G.dx[d] * G.dx[d] / vmax);
+            dt = std::min(dt, min_dt);
+        }
         return dt;
     }
 
@@ -1790,6 +1930,7 @@ struct Sim {
 static void setup_state(StateDef& S, const cmfp_state_desc& d, const cmfp_params& P) {
     S.desc = d;
     S.num_grow = recon_num_grow(d.reconstruction);
+    if (d.kind == CMFP_STATE_HYDRO && d.viscosity) S.num_grow = std::max(S.num_grow, 2);  // MFP_hydro.cpp:108-110
     if (d.kind == CMFP_STATE_HYDRO) {
         S.gas = Gas{d.mass, d.charge, d.gamma};
         S.n_cons = HC_NUM;
