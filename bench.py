@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--n", type=int, default=4096, help="cells per side of the per-GPU block")
     ap.add_argument("--fp", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--tiled-hydro", action="store_true", help="diagnostic: LDS-tiled hydro CTU kernel instead of the wave-marching one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-corner-transport", action="store_true", help="diagnostic: corner_transport=false (not the headline workload)")
     args = ap.parse_args()
@@ -139,7 +140,7 @@ def main():
     dim = 3 if args.workload == "rmi_3d" else 2
     grid = block_grid(dim, world)
     P = build_problem(args.workload, args.n, grid, fp_mode, not args.no_corner_transport)
-    m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=not args.no_fused)
+    m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=(3 if args.tiled_hydro else not args.no_fused))
     m.init_data()
 
     def sync():

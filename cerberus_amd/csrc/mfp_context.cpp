@@ -535,6 +535,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             if (K.states[n] != S.states[n]) return 0;
     }
     // probe coverage (null launches): the tiled 2-D kernel where it applies, else the gather kernels
+    const int tile_flag = c->fused == 3 ? 0x100 : 0;  // 3: the LDS-tiled kernel also where the wave-marching one applies
     std::vector<char> tiled(c->states.size(), 0);
     bool any_gather = false;
     const Ptr3 none{{nullptr, nullptr, nullptr}};
@@ -544,7 +545,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
                 const StatePhys& sp = c->states[A.states[i]].sp;
                 if (sp.kind == CMFP_STATE_HYDRO && sp.visc.kind) return 0;  // viscous fluxes: stage-by-stage kernels only
                 if (c->fused != 2 && c->L->ctu_fused(c->g, sp, nullptr, nullptr, A.corner_transport, dt, c->touches, nullptr,
-                                                     nullptr, 0, c->stream)) {
+                                                     nullptr, 0 | tile_flag, c->stream)) {
                     tiled[A.states[i]] = 1;
                 } else if (c->L->ctu_gather(c->g, sp, nullptr, nullptr, none, none, A.corner_transport, dt, c->touches,
                                             nullptr, nullptr, c->stream)) {
@@ -581,7 +582,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     bool overlap = c->overlap == 2 || (c->overlap == 1 && split_any);
     for (size_t q = 0; q < list.size() && overlap; ++q)
         overlap = tiled[list[q]] && c->L->ctu_fused(c->g, c->states[list[q]].sp, nullptr, nullptr, ctu_flag[q], dt, c->touches,
-                                                    nullptr, nullptr, 1, c->stream);
+                                                    nullptr, nullptr, 1 | tile_flag, c->stream);
     if (overlap && !c->stream2) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
@@ -613,7 +614,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         for (size_t q = 0; q < list.size(); ++q) {
             StateRT& s = c->states[list[q]];
             ProfScope prof(c, slot_of(s), c->stream2, true);
-            c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], 1, c->stream2);
+            c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], 1 | tile_flag, c->stream2);
         }
         HIPCHK(c, hipEventRecord(c->ev_int, c->stream2));
     }
@@ -627,7 +628,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         StateRT& s = c->states[list[q]];
         ProfScope prof(c, slot_of(s), c->stream, !overlap);
         if (tiled[list[q]])
-            c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], overlap ? 2 : 0,
+            c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], (overlap ? 2 : 0) | tile_flag,
                             c->stream);
         else
             c->L->ctu_gather(c->g, s.sp, s.new_data, s.alt, F1, F2, ctu_flag[q], dt, c->touches, c->d_err, slots[q], c->stream);

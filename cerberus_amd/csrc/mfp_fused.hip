@@ -437,9 +437,17 @@ extern "C" void cmfp_debug_stamps(unsigned long long* out, int reset) {
 
 // part: 0 all tiles, 1 interior tiles, 2 the frame of boundary tiles (see TileSel).  Uin == nullptr:
 // part 0 probes coverage, part 1 probes whether the block has interior tiles.
+// defined in mfp_march.hip
+int ctu_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
+              const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st);
+
+// part bit 8 set: the LDS-tiled kernel even where the wave-marching kernel (mfp_march.hip) applies
 int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
               const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st) {
     if (g.dim != 2) return 0;
+    const bool tile_only = part & 0x100;
+    part &= 0xff;
+    if (!tile_only && ctu_march(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, part, st)) return 1;
 #define HY(R, F)                                                                                                    \
     if (sp.recon == R && sp.flux == F)                                                                              \
         return launch2d<HydroF<R, F>, CMFP_HBX, CMFP_HBY>(g, sp.hp, sp, Uin, Uout, do_ctu, dt, touches, err, red, part, st);

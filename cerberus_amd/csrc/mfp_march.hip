@@ -1,0 +1,369 @@
+// mfp_march.hip — wave-marching fused corner-transport-upwind update of a hydro state (2-D).
+//
+// Same work as k_ctu2d of mfp_fused.hip — HydroCTU::calc_spatial_derivative
+// (MFP_CTU_hydro.cpp:142-531) + `new += dU` (MFP_advance.cpp:220-230) in one launch — organised so
+// that nothing is computed twice: one wavefront owns a strip of 64 columns and marches along y, one
+// row per iteration, every lane carrying its column's pipeline in registers:
+//
+//   iteration r:  U(r+1) -> primitives                         (prefetched one row ahead)
+//                 reconstruction + half-step trace of row r    (x-stencil: the neighbouring lanes,
+//                                                               y-stencil: rows r-1, r, r+1 in registers)
+//                 Riemann sweep 1: F_x(r), F_y(r)
+//                 transverse correction: y-face states of row r with F_x(r),
+//                                        x-face states of row r-1 with F_y(r-1) - F_y(r)
+//                 domain-face BCs, Riemann sweep 2: F'_y(r), F'_x(r-1)
+//                 divergence of row r-1, Uout = Uin + dU, optional CFL reduction
+//
+// x-neighbours talk through DPP wave shifts (register to register); there is no LDS and no barrier.
+// A strip updates 60 of its 64 columns (two columns of stencil + transverse ring on each side), a
+// segment of S rows costs S + 2 iterations: 92 % of the lanes' work lands in updated cells against
+// 77 % of the 16 x 16 tile kernel (which also converts the 18 x 18 halo to primitives per tile).
+// Arithmetic per value is the same sequence of device functions as the staged and tiled kernels:
+// STRICT results are identical to them bit for bit.
+#include <cstdlib>
+
+#include "mfp_device.h"
+
+namespace CMFP_NS {
+using namespace cmfp;
+
+// value of the neighbouring lane of the wavefront (wave_shr:1 / wave_shl:1); every lane must execute these
+CMFP_DEV double lane_left(double v) {  // lane l <- lane l - 1
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+CMFP_DEV double lane_right(double v) {  // lane l <- lane l + 1
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+struct MarchBC {
+    int touch[2][2];    // [d][side]: physical (non-periodic) domain face on this block
+    int rule[2][2][5];  // FILL_SKIP / FILL_EVEN / FILL_ODD per primitive comp
+};
+// Cells a launch updates: up to four rectangles (the whole block; its interior; the frame around
+// the interior as four rectangles), each cut into strips of MW columns and segments of `seg` rows.
+struct MarchRect {
+    int ilo, ihi, jlo, jhi;
+    int ns, nseg;  // strips, segments
+    int first;     // index of the rectangle's first wave
+};
+struct MarchSel {
+    int nrect, nwaves, seg;
+    MarchRect r[4];
+};
+static constexpr int MW = 60;  // columns a strip updates
+
+template <class Phys, bool HAS_BC, bool REDUCE>
+__global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
+                                                      double* __restrict__ Uout, double dt, MarchBC bc, int* err, MarchSel sel,
+                                                      unsigned long long* red) {
+    constexpr int RECON = Phys::RECON;
+    static_assert(ReconTraits<RECON>::SL == 3 && Phys::IS_HYDRO, "three-point hydro reconstructions");
+    const int lane = threadIdx.x;
+    // XCD-aware order (see mfp_fused.hip): neighbouring strips, which share stencil columns, run on one XCD
+    const int per = (sel.nwaves + 7) >> 3;
+    int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (w >= sel.nwaves) return;
+    MarchRect R = sel.r[0];
+#pragma unroll
+    for (int t = 1; t < 4; ++t)
+        if (t < sel.nrect && w >= sel.r[t].first) R = sel.r[t];
+    w -= R.first;
+    const int segi = w / R.ns, strip = w - segi * R.ns;
+    const int n0 = g.n[0], n1 = g.n[1];
+    const int i = R.ilo + strip * MW - 2 + lane;  // this lane's column (>= -2)
+    const int ic = i < R.ihi + 2 ? i : R.ihi + 2;  // lanes past the rectangle's stencil reach re-read its last column
+    const int ja = R.jlo + segi * sel.seg;
+    const int jb = (ja + sel.seg - 1 < R.jhi) ? ja + sel.seg - 1 : R.jhi;
+    const bool inner = lane >= 2 && lane <= 61;
+    const bool upd = inner && i <= R.ihi;
+    const double gamma = Phys::gamma_of(P), gm1 = gamma - 1.0;
+    const double kx = 0.5 * dt / g.dx[0], ky = 0.5 * dt / g.dx[1];
+    const double dtdx = dt / g.dx[0], dtdy = dt / g.dx[1];
+    const long col = g.at(ic, 0, 0);
+    bool bad = false;
+
+    auto load_row = [&](int row, double* U) {
+        const long c = col + (long)row * g.sj;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) U[n] = Uin[c + n * g.sc];
+    };
+    // conserved -> {rho, u, v, w, eps = p / (gamma - 1)} (MFP_hydro.cpp:847-862)
+    auto to_prim = [&](const double* U, double* Q) {
+        if (!Phys::cons2prim(P, U, Q)) bad = true;
+        Q[H_P] = f_div(Q[H_P], gm1);
+    };
+
+    double Qa[5], Qb[5], Un[5];
+    {
+        double U[5];
+        load_row(ja - 2, U);
+        to_prim(U, Qa);
+        load_row(ja - 1, U);
+        to_prim(U, Qb);
+        load_row(ja, Un);
+    }
+    // carried from the previous iteration (row r - 1)
+    double xlo_p[5], xhi_p[5];  // traced x-face states, not yet corrected
+    double yhiU_p[5];           // traced high y-face state (sweep 1)
+    double yhiC_p[5];           // the same, transversally corrected (sweep 2)
+    double fy_p[5], fy2_p[5];   // F_y and F'_y on the low y-face
+#pragma unroll
+    for (int n = 0; n < 5; ++n) xlo_p[n] = xhi_p[n] = yhiU_p[n] = yhiC_p[n] = fy_p[n] = fy2_p[n] = 0.0;
+    double red_speed = 2.2250738585072014e-308;  // std::numeric_limits<Real>::min(), MFP_eulerian.cpp:265
+
+    for (int r = ja - 1; r <= jb + 1; ++r) {
+        double Qc[5];
+        to_prim(Un, Qc);
+        {
+            const int rn = r + 2 < jb + 2 ? r + 2 : jb + 2;  // rows past the segment's stencil reach are not touched
+            load_row(rn, Un);
+        }
+        double Uold[5];
+        load_row(r - 1, Uold);  // used once r - 1 >= ja
+
+        // ---- reconstruction + half-step trace of row r (HydroState::calc_reconstruction,
+        //      calc_time_averaged_faces)
+        double xlo[5], xhi[5], ylo[5], yhi[5];
+        {
+            double centre[5], speed[3];
+#pragma unroll
+            for (int n = 0; n < 5; ++n) centre[n] = Qb[n];
+            centre[H_P] = centre[H_P] * gm1;  // restored pressure, MFP_hydro.cpp:1025-1035
+            Phys::speed_from_prim(P, centre, speed);
+            double st[3][5];
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                st[0][n] = lane_left(Qb[n]);
+                st[1][n] = Qb[n];
+                st[2][n] = lane_right(Qb[n]);
+            }
+            hydro_cell_faces<RECON>(gamma, st, xlo, xhi);
+#pragma unroll
+            for (int n = 0; n < 5; ++n) trace_faces(speed[0], kx, centre[n], xlo[n], xhi[n]);
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                st[0][n] = Qa[n];
+                st[2][n] = Qc[n];
+            }
+            hydro_cell_faces<RECON>(gamma, st, ylo, yhi);
+#pragma unroll
+            for (int n = 0; n < 5; ++n) trace_faces(speed[1], ky, centre[n], ylo[n], yhi[n]);
+        }
+
+        // ---- Riemann sweep 1 on the low faces of (i, r)
+        double fx[5], fy[5] = {0, 0, 0, 0, 0};
+        {
+            double L[5];
+#pragma unroll
+            for (int n = 0; n < 5; ++n) L[n] = lane_left(xhi[n]);
+            Phys::riemann(P, 0, L, xlo, fx);
+            if (r >= ja) Phys::riemann(P, 1, yhiU_p, ylo, fy);
+        }
+        double yhiU[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) yhiU[n] = yhi[n];
+
+        // ---- transverse corrections (EulerianState::correct_face_prim MFP_eulerian.cpp:1047-1188,
+        //      per cell: each face state is corrected with the transverse fluxes of its own cell)
+        {
+            double dF[5];
+#pragma unroll
+            for (int n = 0; n < 5; ++n) dF[n] = fx[n] - lane_right(fx[n]);
+            const bool col_in = inner && i >= 0 && i < n0;
+            const bool ok_hi = Phys::correct(P, yhi, kx, dF);
+            const bool ok_lo = Phys::correct(P, ylo, kx, dF);
+            if (col_in && ((!ok_hi && r < n1) || (!ok_lo && r >= 0 && r <= n1))) bad = true;
+        }
+        if (r > ja) {  // x-face states of row r - 1 use F_y(r - 1) - F_y(r)
+            double dF[5];
+#pragma unroll
+            for (int n = 0; n < 5; ++n) dF[n] = fy_p[n] - fy[n];
+            const bool ok_hi = Phys::correct(P, xhi_p, ky, dF);
+            const bool ok_lo = Phys::correct(P, xlo_p, ky, dF);
+            const bool lane_ok = lane >= 1 && lane <= 62;
+            if (lane_ok && ((!ok_hi && i >= -1 && i < n0) || (!ok_lo && i >= 0 && i <= n0))) bad = true;
+        }
+
+        // ---- domain-face BCs (update_face_prim, do_all) + Riemann sweep 2
+        double fy2[5] = {0, 0, 0, 0, 0};
+        if (r >= ja) {
+            double L[5], Rr[5];
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                L[n] = yhiC_p[n];
+                Rr[n] = ylo[n];
+            }
+            if (HAS_BC && bc.touch[1][0] && r == 0) {
+#pragma unroll
+                for (int n = 0; n < 5; ++n)
+                    if (bc.rule[1][0][n]) L[n] = bc.rule[1][0][n] == FILL_ODD ? -Rr[n] : Rr[n];
+            }
+            if (HAS_BC && bc.touch[1][1] && r == n1) {
+#pragma unroll
+                for (int n = 0; n < 5; ++n)
+                    if (bc.rule[1][1][n]) Rr[n] = bc.rule[1][1][n] == FILL_ODD ? -L[n] : L[n];
+            }
+            Phys::riemann(P, 1, L, Rr, fy2);
+        }
+        if (r > ja) {
+            double L[5], Rr[5], fx2[5];
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                L[n] = lane_left(xhi_p[n]);
+                Rr[n] = xlo_p[n];
+            }
+            if (HAS_BC && bc.touch[0][0] && i == 0) {
+#pragma unroll
+                for (int n = 0; n < 5; ++n)
+                    if (bc.rule[0][0][n]) L[n] = bc.rule[0][0][n] == FILL_ODD ? -Rr[n] : Rr[n];
+            }
+            if (HAS_BC && bc.touch[0][1] && i == n0) {
+#pragma unroll
+                for (int n = 0; n < 5; ++n)
+                    if (bc.rule[0][1][n]) Rr[n] = bc.rule[0][1][n] == FILL_ODD ? -L[n] : L[n];
+            }
+            Phys::riemann(P, 0, L, Rr, fx2);
+            // ---- divergence of row r - 1 (calc_divergence MFP_eulerian.cpp:1614-1662), new += dU
+            double Unew[5];
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                const double fxh = lane_right(fx2[n]);
+                double du = 0.0;
+                du += dtdx * (fx2[n] - fxh);
+                du += dtdy * (fy2_p[n] - fy2[n]);
+                Unew[n] = Uold[n] + du;
+            }
+            if (upd) {
+                const long c = col + (long)(r - 1) * g.sj;
+#pragma unroll
+                for (int n = 0; n < 5; ++n) Uout[c + n * g.sc] = Unew[n];
+                if constexpr (REDUCE) {  // EulerianState::get_allowed_time_step MFP_eulerian.cpp:290-296
+                    double s[3];
+                    hydro_speed_from_cons(P.gas, Unew, s);
+                    red_speed = std_max(std_max(red_speed, s[0]), s[1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            Qa[n] = Qb[n];
+            Qb[n] = Qc[n];
+            xlo_p[n] = xlo[n];
+            xhi_p[n] = xhi[n];
+            yhiU_p[n] = yhiU[n];
+            yhiC_p[n] = yhi[n];
+            fy_p[n] = fy[n];
+            fy2_p[n] = fy2[n];
+        }
+    }
+    if (bad) *err = 1;
+    if constexpr (REDUCE) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) red_speed = fmax(red_speed, __shfl_xor(red_speed, o, 64));
+        if (lane == 0) atomicMax(&red[blockIdx.x & 255], (unsigned long long)__double_as_longlong(red_speed));
+    }
+}
+
+static MarchBC make_march_bc(const StatePhys& sp, const int touches[3][2]) {
+    MarchBC b;
+    for (int d = 0; d < 2; ++d)
+        for (int s = 0; s < 2; ++s) {
+            b.touch[d][s] = touches[d][s];
+            for (int n = 0; n < 5; ++n) {
+                const int code = sp.bc[n][d][s];  // MFP_eulerian.cpp:796-835
+                b.rule[d][s][n] = (code == 2 || code == 4 || code == 1) ? FILL_EVEN : (code == -1 ? FILL_ODD : FILL_SKIP);
+            }
+        }
+    return b;
+}
+
+// wave slots of the device at two waves per SIMD (the kernel's register budget)
+static int wave_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        slots = 2048;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            slots = p.multiProcessorCount * 8;
+    }
+    return slots;
+}
+
+template <class Phys>
+static int launch_march(const Geo& g, const typename Phys::Params& P, const StatePhys& sp, const double* Uin, double* Uout,
+                        double dt, const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st) {
+    const int n0 = g.n[0], n1 = g.n[1];
+    if (g.ng[0] < 2 || g.ng[1] < 2) return 0;
+    const bool has_int = n0 >= 5 && n1 >= 5;  // cells whose stencil footprint (+-2) stays inside valid cells
+    if (!Uin) return part == 1 ? has_int : 1;
+    MarchSel sel;
+    sel.nrect = 0;
+    auto add = [&](int ilo, int ihi, int jlo, int jhi) {
+        if (ihi < ilo || jhi < jlo) return;
+        MarchRect& r = sel.r[sel.nrect++];
+        r.ilo = ilo, r.ihi = ihi, r.jlo = jlo, r.jhi = jhi;
+        r.ns = (ihi - ilo + MW) / MW;
+    };
+    if (part == 0 || (part == 2 && !has_int)) {
+        add(0, n0 - 1, 0, n1 - 1);
+    } else if (part == 1) {
+        add(2, n0 - 3, 2, n1 - 3);
+    } else {
+        add(0, n0 - 1, 0, 1);
+        add(0, n0 - 1, n1 - 2, n1 - 1);
+        add(0, 1, 2, n1 - 3);
+        add(n0 - 2, n0 - 1, 2, n1 - 3);
+    }
+    if (sel.nrect == 0) return 1;
+    // segment length: one resident round of waves where the block is large enough for segments of
+    // >= 32 rows, else 32-row segments
+    int strips = 0;
+    for (int q = 0; q < sel.nrect; ++q) strips = strips > sel.r[q].ns ? strips : sel.r[q].ns;
+    static const int seg_env = std::getenv("CMFP_MARCH_SEG") ? std::atoi(std::getenv("CMFP_MARCH_SEG")) : 0;
+    int seg = seg_env;
+    if (seg <= 0) {
+        const int rounds = wave_slots() / strips;  // segments per strip that fit one round
+        seg = rounds > 0 ? (n1 + rounds - 1) / rounds : n1;
+        if (seg < 32) seg = 32;
+    }
+    sel.seg = seg;
+    sel.nwaves = 0;
+    for (int q = 0; q < sel.nrect; ++q) {
+        MarchRect& r = sel.r[q];
+        r.nseg = (r.jhi - r.jlo + seg) / seg;
+        r.first = sel.nwaves;
+        sel.nwaves += r.ns * r.nseg;
+    }
+    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
+    const MarchBC bc = make_march_bc(sp, touches);
+    const dim3 grid(((sel.nwaves + 7) / 8) * 8), block(64);
+#define CMFP_LAUNCH(BC, RED) \
+    hipLaunchKernelGGL((k_ctu_march<Phys, BC, RED>), grid, block, 0, st, g, P, Uin, Uout, dt, bc, err, sel, red)
+    if (red) {
+        if (has_bc) CMFP_LAUNCH(true, true); else CMFP_LAUNCH(false, true);
+    } else {
+        if (has_bc) CMFP_LAUNCH(true, false); else CMFP_LAUNCH(false, false);
+    }
+#undef CMFP_LAUNCH
+    return 1;
+}
+
+// Same contract as ctu_fused (mfp_fused.hip): part 0 all cells, 1 the interior, 2 the frame;
+// Uin == nullptr probes coverage (part 0) / whether an interior exists (part 1).  Returns 0 where the
+// option set is outside this kernel (the caller then uses the tiled kernel).
+int ctu_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
+              const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st) {
+    if (g.dim != 2 || sp.kind != 0 || !do_ctu) return 0;
+#define HY(R, F) \
+    if (sp.recon == R && sp.flux == F) return launch_march<HydroF<R, F>>(g, sp.hp, sp, Uin, Uout, dt, touches, err, red, part, st);
+    HY(1, 0) HY(1, 1) HY(1, 2) HY(2, 0) HY(2, 1) HY(2, 2) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)
+#undef HY
+    return 0;
+}
+
+}  // namespace CMFP_NS

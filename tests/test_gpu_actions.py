@@ -50,7 +50,6 @@ def test_action_dU_and_dt_limits(oracle, case):
 @pytest.mark.parametrize("case", [3, 4, 0])
 def test_fill_patch_matches_oracle(oracle, case):
     import ctypes as C
-    import torch
     name, cfg, _ = small_cases()[case]
     P = config.Problem(cfg)
     ref = oracle.OracleSim(P)
@@ -60,9 +59,9 @@ def test_fill_patch_matches_oracle(oracle, case):
         ptr, ng, ext, nc = m.device_view(s)
         n = nc * ext[0] * ext[1] * ext[2]
         host = np.empty(n)
-        torch.cuda.synchronize()
         import ctypes
         hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipDeviceSynchronize() == 0
         assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(8 * n), 2) == 0
         A = host.reshape(nc, ext[2], ext[1], ext[0])
         G = ref.fill_patch(s)                       # domain grown by the state's own num_grow
@@ -110,11 +109,11 @@ def test_hydro_option_matrix(oracle, recon, flux):
     P = config.Problem(_kh(recon, flux), fp_mode=abi.FP_STRICT)
     ref = oracle.OracleSim(P)
     ref.run(5)
-    for fused in (False, True, 2):
+    for fused in (False, True, 2, 3):
         m = _gpu(P, fused=fused)
         m.run(5)
         tiled = recon in ("minmod", "vanLeer", "MC", "centre")   # the rest: gather kernels only
-        assert m.last_advance_path() == (int(fused) if tiled or not fused else 2)
+        assert m.last_advance_path() == (min(int(fused), 2) if fused == 2 or not fused else (1 if tiled else 2))
         assert np.array_equal(m.download(0), ref.get_state(0)), (recon, flux, fused)
         m.close()
 
@@ -193,6 +192,30 @@ def test_ragged_sizes(oracle):
             assert m.last_advance_path() == int(fused)
             for s in range(3):
                 assert np.array_equal(m.download(s), ref.get_state(s)), (n, s, fused)
+            m.close()
+
+
+@pytest.mark.parametrize("flux,thr", [("HLLC", None), ("HLLE/HLLC", 0.3)])
+def test_marching_kernel_strips_segments_and_walls(oracle, flux, thr):
+    """The wave-marching hydro kernel (mfp_march.hip): blocks wider than one 60-column strip and
+    taller than one segment (CMFP_MARCH_SEG is read when the library first launches it; the
+    default segment is >= 32 rows), sizes that are no multiple of either, slip walls on all four
+    domain faces (update_face_prim on x and y faces), single and split launches: bit-identical to
+    the oracle and to the tiled kernel."""
+    for n in ([61, 33], [125, 70], [180, 37]):
+        cfg = _kh("vanLeer", flux, thr=thr, n=32)
+        cfg["n_cell"] = n
+        cfg["is_periodic"] = [0, 0]
+        wall = {"lo": {"fill_hydro_bc": "slipwall"}, "hi": {"fill_hydro_bc": "slipwall"}}
+        cfg["states"]["fluid"]["bc"] = {"x": wall, "y": wall}
+        P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+        ref = oracle.OracleSim(P)
+        ref.run(4)
+        for fused, overlap in ((True, 1), (True, 2), (3, 1)):
+            m = _gpu(P, fused=fused, overlap=overlap)
+            m.run(4)
+            assert m.last_advance_path() == 1
+            assert np.array_equal(m.download(0), ref.get_state(0)), (n, fused, overlap)
             m.close()
 
 

@@ -18,7 +18,7 @@ def _gpu(problem, **kw):
     return m
 
 
-@pytest.mark.parametrize("fused", [False, True, 2])   # staged / fused (tiled in 2-D, gather else) / gather
+@pytest.mark.parametrize("fused", [False, True, 2, 3])   # staged / fused (2-D: marching hydro + tiled field) / gather / tiled kernels only
 @pytest.mark.parametrize("case", range(5))
 def test_nstep_parity_strict(oracle, case, fused):
     name, cfg, steps = small_cases()[case]
@@ -34,7 +34,7 @@ def test_nstep_parity_strict(oracle, case, fused):
     m.close()
 
 
-@pytest.mark.parametrize("fused", [False, True, 2])   # staged / fused (tiled in 2-D, gather else) / gather
+@pytest.mark.parametrize("fused", [False, True, 2, 3])   # staged / fused (2-D: marching hydro + tiled field) / gather / tiled kernels only
 @pytest.mark.parametrize("case", range(5))
 def test_nstep_parity_fast(oracle, case, fused):
     name, cfg, steps = small_cases()[case]
@@ -50,15 +50,16 @@ def test_nstep_parity_fast(oracle, case, fused):
     m.close()
 
 
+@pytest.mark.parametrize("fused", [True, 3])
 @pytest.mark.parametrize("case", [1, 2, 3])
-def test_split_launches_identical(oracle, case):
+def test_split_launches_identical(oracle, case, fused):
     """overlap=2: interior tiles on the second stream + frame of boundary tiles after the fill,
     on an unsplit block; must equal the oracle bit for bit like the single launch."""
     name, cfg, steps = small_cases()[case]
     P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
     ref = oracle.OracleSim(P)
     dts_ref = ref.run(steps)
-    m = _gpu(P, overlap=2)
+    m = _gpu(P, overlap=2, fused=fused)
     dts = m.run(steps)
     assert m.last_advance_path() == 1
     assert dts == dts_ref
