@@ -188,7 +188,11 @@ def main():
                 if tj.get(key):
                     traffic = tj[key]["ctu_hydro_bytes_per_launch"]
             copy_gbs = hbm_copy_gbs()
-            roof = {"bound": "hbm", "kernel": "k_ctu2d<HydroF<minmod,HLLC>> (fused CTU update of one hydro state)",
+            kname = ("k_ctu2d<HydroF<minmod,HLLC>> (LDS-tiled" if args.tiled_hydro or dim != 2 else
+                     "k_ctu_march<HydroF<minmod,HLLC>> (wave-marching") + " fused CTU update of one hydro state)"
+            if dim == 3:
+                kname = "k_g_flux/k_g_update<HydroF<minmod,HLLC>> (gather kernels, fused CTU update of one hydro state)"
+            roof = {"bound": "hbm", "kernel": kname,
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "attainable_copy_GBs": copy_gbs, "frac_of_attainable": achieved / copy_gbs,
                     "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms / launches,
