@@ -111,6 +111,23 @@ class MFP:
         self._chk(self.L.cmfp_state_download(self.h, s, out.ctypes.data_as(lib.dp)))
         return out
 
+    def write_plotfile(self, path, max_grid_size=None):
+        """MFP::writePlotFile + writePlotFilePost (MFP_io.cpp:305-422, 467-515): AMReX plotfile of
+        the current new-time data that the reference's vis/get_boxlib.py reads; every rank writes
+        its block, rank 0 the headers."""
+        from . import plotfile
+        gather = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            def gather(obj):
+                out = [None] * self.world
+                dist.all_gather_object(out, obj, group=self.pg)
+                return out
+        states = [self.download(s) for s in range(self.n_states)]
+        return plotfile.write_plotfile(path, self.p, states, self.time, self.step, self.block_lo, self.block_n,
+                                       max_grid_size, self.rank, self.world, gather)
+
     def update_download(self, s, which):
         out = np.empty((self.p.n_comp(s),) + self.shape)
         self._chk(self.L.cmfp_update_download(self.h, s, which, out.ctypes.data_as(lib.dp)))
