@@ -1,0 +1,111 @@
+// mfp_march.h — shared pieces of the wave-marching kernels (mfp_march.hip: hydro, mfp_march_field.hip: field).
+#pragma once
+#include <cstdlib>
+
+#include "mfp_device.h"
+
+namespace CMFP_NS {
+using namespace cmfp;
+
+// value of the neighbouring lane of the wavefront (wave_shr:1 / wave_shl:1); every lane must execute these
+CMFP_DEV double lane_left(double v) {  // lane l <- lane l - 1
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+CMFP_DEV double lane_right(double v) {  // lane l <- lane l + 1
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+struct MarchBC {
+    int touch[2][2];     // [d][side]: physical (non-periodic) domain face on this block
+    int rule[2][2][10];  // FILL_SKIP / FILL_EVEN / FILL_ODD per primitive comp
+};
+// Cells a launch updates: up to four rectangles (the whole block; its interior; the frame around
+// the interior as four rectangles), each cut into strips of `mw` columns and segments of `seg` rows.
+struct MarchRect {
+    int ilo, ihi, jlo, jhi;
+    int ns, nseg;  // strips, segments
+    int first;     // index of the rectangle's first wave
+};
+struct MarchSel {
+    int nrect, nwaves, seg;
+    MarchRect r[4];
+};
+
+static inline MarchBC make_march_bc(const StatePhys& sp, const int touches[3][2]) {
+    MarchBC b;
+    for (int d = 0; d < 2; ++d)
+        for (int s = 0; s < 2; ++s) {
+            b.touch[d][s] = touches[d][s];
+            for (int n = 0; n < 10; ++n) {
+                const int code = (n < sp.nc) ? sp.bc[n][d][s] : -666;  // MFP_eulerian.cpp:796-835
+                b.rule[d][s][n] = (code == 2 || code == 4 || code == 1) ? FILL_EVEN : (code == -1 ? FILL_ODD : FILL_SKIP);
+            }
+        }
+    return b;
+}
+
+// wave slots of the device at two waves per SIMD (the kernels' register budget)
+static inline int wave_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        slots = 2048;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            slots = p.multiProcessorCount * 8;
+    }
+    return slots;
+}
+
+// Rectangles, strips and segments of one launch.  ring = 1 + stencil half width (the ghost reach of
+// the update), mw = columns a strip updates, mult = waves per (strip, segment) (field: one per
+// component group).  part 0 all cells, 1 the interior (stencil footprint inside valid cells), 2 the
+// frame around it.  Returns false when the launch is empty.
+static inline bool march_select(const Geo& g, int part, int ring, int mw, int mult, MarchSel& sel) {
+    const int n0 = g.n[0], n1 = g.n[1];
+    const bool has_int = n0 >= 2 * ring + 1 && n1 >= 2 * ring + 1;
+    sel.nrect = 0;
+    auto add = [&](int ilo, int ihi, int jlo, int jhi) {
+        if (ihi < ilo || jhi < jlo) return;
+        MarchRect& r = sel.r[sel.nrect++];
+        r.ilo = ilo, r.ihi = ihi, r.jlo = jlo, r.jhi = jhi;
+        r.ns = (ihi - ilo + mw) / mw;
+    };
+    if (part == 0 || (part == 2 && !has_int)) {
+        add(0, n0 - 1, 0, n1 - 1);
+    } else if (part == 1) {
+        add(ring, n0 - 1 - ring, ring, n1 - 1 - ring);
+    } else {
+        add(0, n0 - 1, 0, ring - 1);
+        add(0, n0 - 1, n1 - ring, n1 - 1);
+        add(0, ring - 1, ring, n1 - 1 - ring);
+        add(n0 - ring, n0 - 1, ring, n1 - 1 - ring);
+    }
+    if (sel.nrect == 0) return false;
+    // segment length: one resident round of waves where the block is large enough for segments of
+    // >= 32 rows, else 32-row segments
+    int strips = 0;
+    for (int q = 0; q < sel.nrect; ++q) strips = strips > sel.r[q].ns ? strips : sel.r[q].ns;
+    static const int seg_env = std::getenv("CMFP_MARCH_SEG") ? std::atoi(std::getenv("CMFP_MARCH_SEG")) : 0;
+    int seg = seg_env;
+    if (seg <= 0) {
+        const int rounds = wave_slots() / (strips * mult);  // segments per strip that fit one round
+        seg = rounds > 0 ? (n1 + rounds - 1) / rounds : n1;
+        if (seg < 32) seg = 32;
+    }
+    sel.seg = seg;
+    sel.nwaves = 0;
+    for (int q = 0; q < sel.nrect; ++q) {
+        MarchRect& r = sel.r[q];
+        r.nseg = (r.jhi - r.jlo + seg) / seg;
+        r.first = sel.nwaves;
+        sel.nwaves += r.ns * r.nseg;
+    }
+    return true;
+}
+
+}  // namespace CMFP_NS

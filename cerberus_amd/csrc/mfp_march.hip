@@ -20,40 +20,9 @@
 // 77 % of the 16 x 16 tile kernel (which also converts the 18 x 18 halo to primitives per tile).
 // Arithmetic per value is the same sequence of device functions as the staged and tiled kernels:
 // STRICT results are identical to them bit for bit.
-#include <cstdlib>
-
-#include "mfp_device.h"
+#include "mfp_march.h"
 
 namespace CMFP_NS {
-using namespace cmfp;
-
-// value of the neighbouring lane of the wavefront (wave_shr:1 / wave_shl:1); every lane must execute these
-CMFP_DEV double lane_left(double v) {  // lane l <- lane l - 1
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-CMFP_DEV double lane_right(double v) {  // lane l <- lane l + 1
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-struct MarchBC {
-    int touch[2][2];    // [d][side]: physical (non-periodic) domain face on this block
-    int rule[2][2][5];  // FILL_SKIP / FILL_EVEN / FILL_ODD per primitive comp
-};
-// Cells a launch updates: up to four rectangles (the whole block; its interior; the frame around
-// the interior as four rectangles), each cut into strips of MW columns and segments of `seg` rows.
-struct MarchRect {
-    int ilo, ihi, jlo, jhi;
-    int ns, nseg;  // strips, segments
-    int first;     // index of the rectangle's first wave
-};
-struct MarchSel {
-    int nrect, nwaves, seg;
-    MarchRect r[4];
-};
 static constexpr int MW = 60;  // columns a strip updates
 
 template <class Phys, bool HAS_BC, bool REDUCE>
@@ -268,77 +237,14 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, typename Phys::Param
     }
 }
 
-static MarchBC make_march_bc(const StatePhys& sp, const int touches[3][2]) {
-    MarchBC b;
-    for (int d = 0; d < 2; ++d)
-        for (int s = 0; s < 2; ++s) {
-            b.touch[d][s] = touches[d][s];
-            for (int n = 0; n < 5; ++n) {
-                const int code = sp.bc[n][d][s];  // MFP_eulerian.cpp:796-835
-                b.rule[d][s][n] = (code == 2 || code == 4 || code == 1) ? FILL_EVEN : (code == -1 ? FILL_ODD : FILL_SKIP);
-            }
-        }
-    return b;
-}
-
-// wave slots of the device at two waves per SIMD (the kernel's register budget)
-static int wave_slots() {
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        slots = 2048;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-            slots = p.multiProcessorCount * 8;
-    }
-    return slots;
-}
-
 template <class Phys>
 static int launch_march(const Geo& g, const typename Phys::Params& P, const StatePhys& sp, const double* Uin, double* Uout,
                         double dt, const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st) {
-    const int n0 = g.n[0], n1 = g.n[1];
     if (g.ng[0] < 2 || g.ng[1] < 2) return 0;
-    const bool has_int = n0 >= 5 && n1 >= 5;  // cells whose stencil footprint (+-2) stays inside valid cells
+    const bool has_int = g.n[0] >= 5 && g.n[1] >= 5;  // cells whose stencil footprint (+-2) stays inside valid cells
     if (!Uin) return part == 1 ? has_int : 1;
     MarchSel sel;
-    sel.nrect = 0;
-    auto add = [&](int ilo, int ihi, int jlo, int jhi) {
-        if (ihi < ilo || jhi < jlo) return;
-        MarchRect& r = sel.r[sel.nrect++];
-        r.ilo = ilo, r.ihi = ihi, r.jlo = jlo, r.jhi = jhi;
-        r.ns = (ihi - ilo + MW) / MW;
-    };
-    if (part == 0 || (part == 2 && !has_int)) {
-        add(0, n0 - 1, 0, n1 - 1);
-    } else if (part == 1) {
-        add(2, n0 - 3, 2, n1 - 3);
-    } else {
-        add(0, n0 - 1, 0, 1);
-        add(0, n0 - 1, n1 - 2, n1 - 1);
-        add(0, 1, 2, n1 - 3);
-        add(n0 - 2, n0 - 1, 2, n1 - 3);
-    }
-    if (sel.nrect == 0) return 1;
-    // segment length: one resident round of waves where the block is large enough for segments of
-    // >= 32 rows, else 32-row segments
-    int strips = 0;
-    for (int q = 0; q < sel.nrect; ++q) strips = strips > sel.r[q].ns ? strips : sel.r[q].ns;
-    static const int seg_env = std::getenv("CMFP_MARCH_SEG") ? std::atoi(std::getenv("CMFP_MARCH_SEG")) : 0;
-    int seg = seg_env;
-    if (seg <= 0) {
-        const int rounds = wave_slots() / strips;  // segments per strip that fit one round
-        seg = rounds > 0 ? (n1 + rounds - 1) / rounds : n1;
-        if (seg < 32) seg = 32;
-    }
-    sel.seg = seg;
-    sel.nwaves = 0;
-    for (int q = 0; q < sel.nrect; ++q) {
-        MarchRect& r = sel.r[q];
-        r.nseg = (r.jhi - r.jlo + seg) / seg;
-        r.first = sel.nwaves;
-        sel.nwaves += r.ns * r.nseg;
-    }
+    if (!march_select(g, part, 2, MW, 1, sel)) return 1;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
     const MarchBC bc = make_march_bc(sp, touches);
     const dim3 grid(((sel.nwaves + 7) / 8) * 8), block(64);
