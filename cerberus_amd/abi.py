@@ -4,6 +4,7 @@ import ctypes as C
 MAX_DIM = 3
 MAX_COMP = 10
 MAX_ACTION_STATES = 8
+MAX_TRACERS = 2
 
 # cmfp_status
 OK, ERR_INVALID, ERR_HIP, ERR_PHYSICS, ERR_NODEVICE = 0, -1, -2, -3, -4
@@ -68,6 +69,7 @@ class StateDesc(C.Structure):
         ("visc_S", C.c_double),
         ("visc_n", C.c_double),
         ("visc_Pr", C.c_double),
+        ("n_tracers", C.c_int),
         ("bc", ((C.c_int * 2) * MAX_DIM) * MAX_COMP),
     ]
 

@@ -34,8 +34,8 @@ def _get(bc_def, d, side, key, default):
         return default
 
 
-def hydro_bc(bc_def, dim, periodic):
-    """bc[comp 0..4][d][side] for {rho, x_mom, y_mom, z_mom, nrg}."""
+def hydro_bc(bc_def, dim, periodic, n_tracers=0):
+    """bc[comp 0..4 + n_tracers][d][side] for {rho, x_mom, y_mom, z_mom, nrg, tracer_i}."""
     out = [[[abi.BC_BOGUS, abi.BC_BOGUS] for _ in range(abi.MAX_DIM)] for _ in range(abi.MAX_COMP)]
     for d in range(dim):
         for side in range(2):
@@ -47,6 +47,8 @@ def hydro_bc(bc_def, dim, periodic):
             t = 0 if periodic[d] else HYDRO_BC_NAMES[name]      # MFP_hydro.cpp:454-459
             out[0][d][side] = SCALAR_BC[t]
             out[4][d][side] = SCALAR_BC[t]
+            for i in range(n_tracers):                          # bc_set.push_back(&set_scalar_bc), MFP_hydro.cpp:323
+                out[5 + i][d][side] = SCALAR_BC[t]
             for v in range(3):                                  # set_{x,y,z}_vel_bc MFP_bc.cpp:43-89
                 out[1 + v][d][side] = NORM_VEL_BC[t] if v == d else TANG_VEL_BC[t]
     return out

@@ -55,6 +55,28 @@ def update_ref(cfg):
                 rho_ref=rho_ref, u_ref=u_ref, T_ref=T_ref)
 
 
+def gas_n_tracers(gas):
+    """HydroGas::n_tracers = n_species - 1 (MFP_hydro_gas.H:16-17): the length of the mass list."""
+    m = gas["mass"]
+    return len(m) - 1 if isinstance(m, (list, tuple)) else 0
+
+
+def gas_scalar(gas, key):
+    """mass / charge / gamma of the gas.  Lists (several species) are taken where every entry is the
+    same (mass_const, charge_const, gamma_const, MFP_thermally_perfect_gas.cpp:33-35: the tracers are
+    then passive scalars); true mixtures are outside the built path."""
+    v = gas[key]
+    if isinstance(v, (list, tuple)):
+        if len(v) != (gas_n_tracers(gas) + 1):
+            raise ValueError("'mass', 'charge' and 'gamma' must have the same number of components")  # :37-40
+        if any(float(x) != float(v[0]) for x in v):
+            raise NotImplementedError("multi-species mixtures with different mass / charge / gamma are not built yet")
+        if len(v) - 1 > abi.MAX_TRACERS:
+            raise NotImplementedError(f"at most {abi.MAX_TRACERS} tracers")
+        return float(v[0])
+    return float(v)
+
+
 class Problem:
     """Sorted states/actions and everything cmfp_create needs."""
 
@@ -112,10 +134,8 @@ class Problem:
                 gas = sd["gas"]
                 if gas.get("type", "thermally_perfect") != "thermally_perfect":
                     raise NotImplementedError("only the thermally_perfect gas is on the built path")
-                for key in ("mass", "charge", "gamma"):
-                    if isinstance(gas[key], (list, tuple)):
-                        raise NotImplementedError("multi-species (tracer) hydro states are not built yet")
-                d.mass, d.charge, d.gamma = float(gas["mass"]), float(gas["charge"]), float(gas["gamma"])
+                d.mass, d.charge, d.gamma = (gas_scalar(gas, k) for k in ("mass", "charge", "gamma"))
+                d.n_tracers = gas_n_tracers(gas)
                 d.flux = abi.FLUX[sd["flux"]]
                 if d.flux == abi.FLUX["RankineHugoniot"]:
                     raise ValueError("hydro state with a field flux")
@@ -144,7 +164,7 @@ class Problem:
                             ok = d.visc_mu0 > 0 and d.visc_T0 > 0 and d.visc_n > 0
                     if not ok:
                         raise ValueError(f"{visc['type']} input coefficients non-physical")
-                table = bc.hydro_bc(sd.get("bc", {}), self.dim, self.periodic)
+                table = bc.hydro_bc(sd.get("bc", {}), self.dim, self.periodic, d.n_tracers)
             elif sd["type"] == "field":
                 d.kind = abi.STATE_FIELD
                 d.mass, d.charge, d.gamma = 1.0, 0.0, 1.0
@@ -206,7 +226,8 @@ class Problem:
         return arr
 
     def n_comp(self, s):
-        return 5 if self.cfg["states"][self.state_names[s]]["type"] == "hydro" else 10
+        sd = self.cfg["states"][self.state_names[s]]
+        return 5 + gas_n_tracers(sd["gas"]) if sd["type"] == "hydro" else 10
 
     # -- initial data ----------------------------------------------------
     def cell_centres(self, lo=None, n=None):
@@ -242,7 +263,8 @@ class Problem:
                 out[c] = self._eval(val.get(name), dat, shape, FIELD_DEFAULT.get(name, 0.0))
             return out
         gas = sd["gas"]
-        m, g = float(gas["mass"]), float(gas["gamma"])
+        m, g = gas_scalar(gas, "mass"), gas_scalar(gas, "gamma")
+        nt = gas_n_tracers(gas)
         rho = self._eval(val.get("rho"), dat, shape) if "rho" in val else None
         if rho is None and "nd" in val:                       # init_from_number_density, MFP_hydro.cpp:113-120
             rho = self._eval(val["nd"], dat, shape) * m
@@ -261,7 +283,12 @@ class Problem:
         p = np.where(c, rho * T / m, p)
         if np.any(rho <= 0) or np.any(p <= 0):
             raise ValueError("Primitive values outside of physical bounds!!")
-        out = np.empty((5,) + shape)
+        out = np.empty((5 + nt,) + shape)
+        alpha = val.get("alpha", [])
+        if not isinstance(alpha, (list, tuple)):
+            alpha = [alpha] * nt
+        for i in range(nt):                                   # tracer = alpha * rho, MFP_thermally_perfect_gas.cpp:243-245
+            out[5 + i] = self._eval(alpha[i] if i < len(alpha) else None, dat, shape) * rho
         out[0] = rho
         out[1] = u * rho
         out[2] = v * rho

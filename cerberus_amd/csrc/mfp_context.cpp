@@ -544,6 +544,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             for (int i = 0; i < A.n_states; ++i) {
                 const StatePhys& sp = c->states[A.states[i]].sp;
                 if (sp.kind == CMFP_STATE_HYDRO && sp.visc.kind) return 0;  // viscous fluxes: stage-by-stage kernels only
+                if (sp.kind == CMFP_STATE_HYDRO && sp.hp.nt) return 0;      // passive scalars: stage-by-stage kernels only
                 if (c->fused != 2 && c->L->ctu_fused(c->g, sp, nullptr, nullptr, A.corner_transport, dt, c->touches, nullptr,
                                                      nullptr, 0 | tile_flag, c->stream)) {
                     tiled[A.states[i]] = 1;
@@ -745,7 +746,14 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
                             states[s].visc_Pr};
         }
         if (sp.kind == CMFP_STATE_HYDRO) {
-            sp.nc = sp.nq = 5;
+            if (states[s].n_tracers < 0 || states[s].n_tracers > CMFP_MAX_TRACERS)
+                return fail(c, CMFP_ERR_INVALID, "n_tracers must be 0..2");
+            if (states[s].n_tracers && sp.flux == CMFP_FLUX_HYBRID_HLL)
+                return fail(c, CMFP_ERR_INVALID, "HLLE/HLLC with tracers: the reference leaves the blended tracer fluxes undefined (MFP_hybrid_hll.cpp:43-45)");
+            if (states[s].n_tracers && states[s].viscosity)
+                return fail(c, CMFP_ERR_INVALID, "viscous fluxes with tracers are not supported");
+            sp.nc = sp.nq = 5 + states[s].n_tracers;
+            sp.hp.nt = states[s].n_tracers;
             if (sp.flux != CMFP_FLUX_HLLC && sp.flux != CMFP_FLUX_HLLE && sp.flux != CMFP_FLUX_HYBRID_HLL)
                 return fail(c, CMFP_ERR_INVALID, "hydro flux must be HLLC, HLLE or HLLE/HLLC");
             if (!(states[s].mass != 0.0) || !(states[s].gamma != 0.0) || states[s].gamma == 1.0)

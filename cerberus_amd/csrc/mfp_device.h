@@ -272,8 +272,19 @@ CMFP_DEV void hydro_speed_from_prim(const GasP& G, const double* Q, double* s) {
 }
 
 // ------------------------------------------------------------ Riemann: hydro
+// What the passive-scalar (tracer) fluxes need from a hydro Riemann solve: HLLC (MFP_hllc.cpp:100,
+// 111-137,147-173,183): side K the flux was taken from, its normal velocity and density, and in a
+// star region S_K and (S_K - u_K) / (S_K - S_star); HLLE (MFP_hydro_hlle.cpp:75-118): the branch,
+// sL, sR and the normal velocities and densities of both sides.
+struct HllAux {
+    int branch;      // HLLC: 0 pure state, 1 star state.  HLLE: 0 left, 1 middle, 2 right
+    bool useL;       // HLLC: the state comes from the left side
+    double S_K, ratio;
+    double sL, sR;
+};
+
 // HydroHLLC::solve MFP_hllc.cpp:30-185.  L, R in the face-normal frame.
-CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double gamR, double* F) {
+CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double gamR, double* F, HllAux* aux = nullptr) {
     double rhoL = L[H_RHO], uL = L[H_U], vL = L[H_V], wL = L[H_W], pL = L[H_P];
     double nrgL = f_div(pL, gamL - 1) + 0.5 * rhoL * (uL * uL + vL * vL + wL * wL);
     double rhoR = R[H_RHO], uR = R[H_U], vR = R[H_V], wR = R[H_W], pR = R[H_P];
@@ -324,7 +335,14 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
     const double fv4 = u * (nrg + p);
     if (starL || starR) {
         const double sv0 = rho, sv1 = rho * u, sv2 = rho * v, sv3 = rho * w, sv4 = nrg;
-        const double coeff = rho * f_div(S_K - u, S_K - S_star);
+        const double ratio = f_div(S_K - u, S_K - S_star);
+        const double coeff = rho * ratio;
+        if (aux) {
+            aux->branch = 1;
+            aux->useL = useL;
+            aux->S_K = S_K;
+            aux->ratio = ratio;
+        }
         const double ss0 = coeff;
         const double ss1 = coeff * S_star;
         const double ss2 = coeff * v;
@@ -341,6 +359,10 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
         F[3] = fv3 + S_K * (ss3 - sv3);
         F[4] = fv4 + S_K * (ss4 - sv4);
     } else {
+        if (aux) {
+            aux->branch = 0;
+            aux->useL = useL;
+        }
         F[0] = fv0;
         F[1] = fv1;
         F[2] = fv2;
@@ -348,9 +370,17 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
         F[4] = fv4;
     }
 }
+// tracer flux of HydroHLLC::solve: aL, aR = alpha on the two sides (face-normal frame states L, R)
+CMFP_DEV double hllc_tracer_flux(const HllAux& x, const double* L, const double* R, double aL, double aR) {
+    const double rho = x.useL ? L[H_RHO] : R[H_RHO], u = x.useL ? L[H_U] : R[H_U];
+    const double tr = (x.useL ? aL : aR) * rho;  // trK = alpha_K * rho_K  :46-48,62-64
+    const double fv = u * tr;
+    if (x.branch == 0) return fv;
+    return fv + x.S_K * (tr * x.ratio - tr);
+}
 
 // HydroHLLE::solve MFP_hydro_hlle.cpp:30-120
-CMFP_DEV void hlle_solve(const double* L, const double* R, double gamL, double gamR, double* F) {
+CMFP_DEV void hlle_solve(const double* L, const double* R, double gamL, double gamR, double* F, HllAux* aux = nullptr) {
     double rhoL = L[H_RHO], uL = L[H_U], vL = L[H_V], wL = L[H_W], pL = L[H_P];
     double nrgL = f_div(pL, gamL - 1) + 0.5 * rhoL * (uL * uL + vL * vL + wL * wL);
     double aL = f_sqrt(f_div(gamL * pL, rhoL));
@@ -360,6 +390,11 @@ CMFP_DEV void hlle_solve(const double* L, const double* R, double gamL, double g
 
     double sL = std_min(uL - aL, uR - aR);
     double sR = std_max(uL + aL, uR + aR);
+    if (aux) {
+        aux->sL = sL;
+        aux->sR = sR;
+        aux->branch = (sL >= 0.0) ? 0 : ((sL <= 0.0) && (sR >= 0.0)) ? 1 : 2;
+    }
 
     if (sL >= 0.0) {
         F[0] = rhoL * uL;
@@ -400,6 +435,15 @@ CMFP_DEV void hlle_solve(const double* L, const double* R, double gamL, double g
     }
 }
 
+// tracer flux of HydroHLLE::solve
+CMFP_DEV double hlle_tracer_flux(const HllAux& x, const double* L, const double* R, double aL, double aR) {
+    const double trL = aL * L[H_RHO], trR = aR * R[H_RHO];
+    if (x.branch == 0) return L[H_U] * trL;
+    if (x.branch == 2) return R[H_U] * trR;
+    const double fl = L[H_U] * trL, fr = R[H_U] * trR;
+    return f_div(x.sR * fl - x.sL * fr + x.sL * x.sR * (trR - trL), x.sR - x.sL);
+}
+
 // PressureJumpShockDetector::solve MFP_hydro_shockdetector.cpp:35-44
 CMFP_DEV double shock_detect(const double* L, const double* R, double thr) {
     double pL = L[H_P], pR = R[H_P];
@@ -434,6 +478,20 @@ template <int FLUX> CMFP_DEV void hydro_riemann(const double* L, const double* R
         double shk = 0.0;
         if (thr > 0) shk = shock_detect(L, R, thr);
         hybrid_solve(L, R, gam, gam, shk, F);
+    }
+}
+
+// hydro face flux incl. nt passive scalars: L, R carry alpha behind the five primitives, F the tracer
+// fluxes behind the five conserved fluxes (HLLC / HLLE; the hybrid solver leaves tracer fluxes
+// undefined in the reference, quirk Q5, and is refused with tracers)
+template <int FLUX> CMFP_DEV void hydro_riemann_tracers(const double* L, const double* R, double gam, int nt, double* F) {
+    HllAux x;
+    if (FLUX == 0) {
+        hllc_solve(L, R, gam, gam, F, &x);
+        for (int t = 0; t < nt; ++t) F[5 + t] = hllc_tracer_flux(x, L, R, L[5 + t], R[5 + t]);
+    } else {
+        hlle_solve(L, R, gam, gam, F, &x);
+        for (int t = 0; t < nt; ++t) F[5 + t] = hlle_tracer_flux(x, L, R, L[5 + t], R[5 + t]);
     }
 }
 

@@ -59,6 +59,10 @@ __global__ void k_prim(Geo g, IBox box, HydroParams hp, const double* __restrict
         if (!hydro_cons2prim(hp.gas, u, q)) *err = 1;
 #pragma unroll
         for (int n = 0; n < 5; ++n) Q[t + n * g.sc] = q[n];
+        if (hp.nt) {  // alpha = tracer * rhoinv (MFP_thermally_perfect_gas.cpp:212-214)
+            const double rhoinv = f_rcp(u[0]);
+            for (int n = 5; n < 5 + hp.nt; ++n) Q[t + n * g.sc] = U[t + n * g.sc] * rhoinv;
+        }
     } else {
 #pragma unroll
         for (int n = 0; n < 10; ++n) Q[t + n * g.sc] = U[t + n * g.sc];
@@ -129,6 +133,20 @@ __global__ void k_recon(Geo g, IBox box, HydroParams hp, FieldParams fp, const d
             plo[c0 + n * g.sc] = lo[n];
             phi[c0 + n * g.sc] = hi[n];
         }
+        if (HYDRO) {
+            // passive scalars: alpha -+ slope / 2 (MFP_hydro.cpp:982-995), traced like every primitive
+            for (int n = 5; n < 5 + hp.nt; ++n) {
+                double st[SL];
+#pragma unroll
+                for (int s = 0; s < SL; ++s) st[s] = Q[c0 + (long)(s - off) * str[d] + n * g.sc];
+                const double phi_alpha = recon_slope<RECON>(st);
+                double alo = st[off] - 0.5 * phi_alpha;
+                double ahi = st[off] + 0.5 * phi_alpha;
+                if (do_ctu) trace_faces(speed[d], 0.5 * dt / g.dx[d], st[off], alo, ahi);
+                plo[c0 + n * g.sc] = alo;
+                phi[c0 + n * g.sc] = ahi;
+            }
+        }
     }
 }
 
@@ -173,6 +191,27 @@ __global__ void k_fluxes(Geo g, IBox fbox, int d, HydroParams hp, FieldParams fp
         L[n] = rhi[cm + n * g.sc];
         R[n] = rlo[c + n * g.sc];
     }
+    if (HYDRO && hp.nt > 0) {
+        // hydro state with passive scalars: the same solve plus the tracer fluxes
+        if constexpr (HYDRO && FLUX != 2) {
+            double Lt[5 + 2], Rt[5 + 2], Ft[5 + 2];
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                Lt[n] = L[n];
+                Rt[n] = R[n];
+            }
+            for (int n = 5; n < 5 + hp.nt; ++n) {
+                Lt[n] = rhi[cm + n * g.sc];
+                Rt[n] = rlo[c + n * g.sc];
+            }
+            rot_g2l(Lt, H_U, d);
+            rot_g2l(Rt, H_U, d);
+            hydro_riemann_tracers<FLUX>(Lt, Rt, hp.gas.gamma, hp.nt, Ft);
+            rot_l2g(Ft, 1, d);
+            for (int n = 0; n < 5 + hp.nt; ++n) flux[c + n * g.sc] = 0.0 + Ft[n];
+        }
+        return;
+    }
     if (HYDRO) {
         HydroPhys<1, FLUX>::riemann(hp, d, L, R, F);
     } else {
@@ -202,9 +241,25 @@ __global__ void k_correct(Geo g, IBox faces, int d1, HydroParams hp, double* __r
         Lp[n] = rhi[cm + n * g.sc];
         Rp[n] = rlo[c + n * g.sc];
     }
+    const int nt = HYDRO ? hp.nt : 0;
+    double La[2] = {0, 0}, Ra[2] = {0, 0};  // alpha of the two face states
+    for (int t = 0; t < nt; ++t) {
+        La[t] = rhi[cm + (5 + t) * g.sc];
+        Ra[t] = rlo[c + (5 + t) * g.sc];
+    }
     for (int dd = 1; dd < g.dim; ++dd) {
         const int d2 = (d1 + dd) % g.dim;
         const double* __restrict__ f = flux.p[d2];
+        // passive scalars: tracer = alpha * rho, += the transverse flux difference, alpha = tracer * rhoinv
+        // with the corrected density (prim2cons / cons2prim, MFP_thermally_perfect_gas.cpp:212-214,243-245)
+        double Lt[2], Rt[2];
+        for (int t = 0; t < nt; ++t) {
+            const int n = 5 + t;
+            Lt[t] = La[t] * Lp[H_RHO];
+            Rt[t] = Ra[t] * Rp[H_RHO];
+            Lt[t] += 0.5 * dt / g.dx[d2] * (f[cm + n * g.sc] - f[cm + str[d2] + n * g.sc]);
+            Rt[t] += 0.5 * dt / g.dx[d2] * (f[c + n * g.sc] - f[c + str[d2] + n * g.sc]);
+        }
         if (HYDRO) {
             hydro_prim2cons(hp.gas, Lp, Lc);
             hydro_prim2cons(hp.gas, Rp, Rc);
@@ -230,6 +285,13 @@ __global__ void k_correct(Geo g, IBox faces, int d1, HydroParams hp, double* __r
         if (HYDRO) {
             if (!hydro_cons2prim(hp.gas, Lc, Lp)) *err = 1;
             if (!hydro_cons2prim(hp.gas, Rc, Rp)) *err = 1;
+            if (nt) {
+                const double rinvL = f_rcp(Lc[0]), rinvR = f_rcp(Rc[0]);
+                for (int t = 0; t < nt; ++t) {
+                    La[t] = Lt[t] * rinvL;
+                    Ra[t] = Rt[t] * rinvR;
+                }
+            }
         } else {
 #pragma unroll
             for (int n = 0; n < 10; ++n) {
@@ -242,6 +304,10 @@ __global__ void k_correct(Geo g, IBox faces, int d1, HydroParams hp, double* __r
     for (int n = 0; n < NQ; ++n) {
         rhi[cm + n * g.sc] = Lp[n];
         rlo[c + n * g.sc] = Rp[n];
+    }
+    for (int t = 0; t < nt; ++t) {
+        rhi[cm + (5 + t) * g.sc] = La[t];
+        rlo[c + (5 + t) * g.sc] = Ra[t];
     }
 }
 
@@ -1043,6 +1109,11 @@ static FillRules face_rules(const StatePhys& sp, int d, int side) {
     FillRules r;
     for (int n = 0; n < 10; ++n) {
         int bc = (n < sp.nc) ? sp.bc[n][d][side] : -666;
+        // hydro with tracers: fill_bc[5], fill_bc[6] (the tracer entries) index the primitives T and
+        // gamma in the reference (MFP_hydro.cpp:448-463 sets the first n_cons of n_prim entries), which
+        // never reach the conserved result with a single-species gas; alpha (primitive 8+) keeps its
+        // reconstructed face value.  The carried slots 5+ are alpha: skip them.
+        if (sp.kind == 0 && n >= 5) bc = -666;
         r.rule[n] = (bc == 2 || bc == 4 || bc == 1) ? FILL_EVEN : (bc == -1 ? FILL_ODD : FILL_SKIP);
     }
     return r;

@@ -10,6 +10,7 @@ struct GasP {
 struct HydroParams {
     GasP gas;
     double shock_threshold;
+    int nt;  // passive scalars (n_tracers): comps 5 .. 5 + nt - 1 of the conserved / primitive / flux arrays
 };
 struct FieldParams {
     double c0;       // MFP::lightspeed

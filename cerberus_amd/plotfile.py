@@ -62,7 +62,7 @@ def state_plot_data(P, s, U):
             out[f"{v}-{sname}"] = U[n]
         return out
     gas = sd["gas"]
-    mass, charge, gamma = float(gas["mass"]), float(gas["charge"]), float(gas["gamma"])
+    mass, charge, gamma = (config.gas_scalar(gas, k) for k in ("mass", "charge", "gamma"))
     ez = float(sd.get("effective_zero", 1e-14))
     ok = U[0] >= ez                                   # :700 cells below effective_zero stay 0
     rho = np.where(ok, U[0], 1.0)
@@ -95,8 +95,9 @@ def state_info(P, s):
     if sd["type"] == "hydro":
         gas = sd["gas"]
         js["cons_names"] = list(HYDRO_CONS)
-        js["gas"] = {"mass": [float(gas["mass"])], "charge": [float(gas["charge"])], "comp_names": [],
-                     "type": gas.get("type", "thermally_perfect"), "gamma": [float(gas["gamma"])]}
+        nsp = config.gas_n_tracers(gas) + 1
+        js["gas"] = {k: [config.gas_scalar(gas, k)] * nsp for k in ("mass", "charge", "gamma")}
+        js["gas"].update({"comp_names": [], "type": gas.get("type", "thermally_perfect")})
         if "viscosity" in sd:
             js["viscosity"] = dict(sd["viscosity"])
     else:

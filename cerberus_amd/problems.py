@@ -83,6 +83,19 @@ def kelvin_helmholtz_2d(n=2048, flux="HLLC", recon="minmod"):
     }
 
 
+def with_tracers(cfg, state, alphas):
+    """Gives hydro state `state` of cfg len(alphas) passive scalars: a gas of len(alphas) + 1 species
+    with equal mass, charge and gamma (n_tracers = n_species - 1, MFP_hydro_gas.H:16-17) and
+    value.alpha = alphas (numbers or functions of the cell-centre dict)."""
+    sd = cfg["states"][state]
+    n = len(alphas) + 1
+    gas = sd["gas"]
+    for k in ("mass", "charge", "gamma"):
+        gas[k] = [gas[k]] * n
+    sd["value"]["alpha"] = list(alphas)
+    return cfg
+
+
 def orszag_tang_two_fluid_2d(n=4096, solver="explicit", source="plasma5", collisions=False):
     gam = 5 / 3
     c = 20.0

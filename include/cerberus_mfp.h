@@ -21,6 +21,7 @@ extern "C" {
 #define CMFP_MAX_DIM 3
 #define CMFP_MAX_COMP 10
 #define CMFP_MAX_ACTION_STATES 8
+#define CMFP_MAX_TRACERS 2
 
 typedef enum {
     CMFP_OK = 0,
@@ -139,8 +140,12 @@ typedef struct {
      * mu0 / (rho_ref x_ref u_ref), T0 / T_ref, S / T_ref.  2-D and 1-D blocks only. */
     int viscosity;          /* cmfp_viscosity */
     double visc_mu0, visc_T0, visc_S, visc_n, visc_Pr;
+    /* hydro: passive scalars `alpha` of a single-species gas (value.alpha = {...},
+     * HydroState::n_tracers MFP_hydro.cpp:296-323): conserved comps 5 .. 5 + n_tracers - 1 hold
+     * rho * alpha (MFP_thermally_perfect_gas.cpp:212-214,243-245).  0 <= n_tracers <= 2. */
+    int n_tracers;
     /* BCRec per conserved component: bc[comp][dim][0=lo,1=hi] (cmfp_bc).
-     * hydro uses comps 0..4, field 0..9. */
+     * hydro uses comps 0..4 (+ n_tracers), field 0..9. */
     int bc[CMFP_MAX_COMP][CMFP_MAX_DIM][2];
 } cmfp_state_desc;
 

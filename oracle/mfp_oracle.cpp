@@ -227,6 +227,7 @@ static void recon_face_values(int r, const Real* stencil, Real& lo, Real& hi) {
 // MFP_hydro_gas.cpp:54,78,102,129 always apply)
 struct Gas {
     Real mass, charge, gamma;
+    int nt = 0;  // n_tracers: passive scalars alpha (mass, charge, gamma stay the constants of species 0)
     Real cp() const { return gamma / (mass * (gamma - 1)); }  // :127
 };
 
@@ -266,6 +267,7 @@ static bool gas_cons2prim(const Gas& G, const Real* U, Real* Q) {
     Q[Temp] = T;
     Q[Gamma] = g;
     Q[SpHeat] = cp;
+    for (int i = 0; i < G.nt; ++i) { Q[HP_NUM + i] = U[HC_NUM + i] * rhoinv; }  // :212-214
     return prim_valid(Q);
 }
 
@@ -289,6 +291,7 @@ static void gas_prim2cons(const Gas& G, const Real* Q, Real* U) {
     U[Ymom] = my;
     U[Zmom] = mz;
     U[Eden] = ed;
+    for (int i = 0; i < G.nt; ++i) { U[HC_NUM + i] = Q[HP_NUM + i] * rho; }  // :243-245
 }
 
 // ThermallyPerfectGas::get_speed_from_cons :294-317 (all three components;
@@ -324,8 +327,8 @@ static void gas_speed_from_prim(const Gas& G, const Real* Q, Real* s) {
 
 // ---------------------------------------------------------------------------
 // Riemann solvers
-// HydroHLLC::solve  hydro/riemann/MFP_hllc.cpp:30-185 (n_alpha = 0)
-static void hllc_solve(const Real* L, const Real* R, Real* F) {
+// HydroHLLC::solve  hydro/riemann/MFP_hllc.cpp:30-185; nt = n_alpha tracers behind the 8 primitives
+static void hllc_solve(const Real* L, const Real* R, Real* F, int nt = 0) {
     Real rhoL = L[PDensity];
     Real uL = L[Xvel];
     Real vL = L[Yvel];
@@ -334,6 +337,8 @@ static void hllc_solve(const Real* L, const Real* R, Real* F) {
     Real gamL = L[Gamma];
     Real nrgL = pL / (gamL - 1) + 0.5 * rhoL * (uL * uL + vL * vL + wL * wL);
     Real aL = sqrt(gamL * pL / rhoL);
+    Real trL[CMFP_MAX_TRACERS], trR[CMFP_MAX_TRACERS];
+    for (int i = 0; i < nt; ++i) trL[i] = L[HP_NUM + i] * rhoL;  // :46-48
 
     Real rhoR = R[PDensity];
     Real uR = R[Xvel];
@@ -343,6 +348,7 @@ static void hllc_solve(const Real* L, const Real* R, Real* F) {
     Real gamR = R[Gamma];
     Real nrgR = pR / (gamR - 1) + 0.5 * rhoR * (uR * uR + vR * vR + wR * wR);
     Real aR = sqrt(gamR * pR / rhoR);
+    for (int i = 0; i < nt; ++i) trR[i] = R[HP_NUM + i] * rhoR;  // :62-64
 
     Real rho_bar = 0.5 * (rhoL + rhoR);
     Real a_bar = 0.5 * (aL + aR);
@@ -373,6 +379,7 @@ static void hllc_solve(const Real* L, const Real* R, Real* F) {
         F[Ymom] = rhoL * uL * vL;
         F[Zmom] = rhoL * uL * wL;
         F[Eden] = uL * (nrgL + pL);
+        for (int i = 0; i < nt; ++i) { F[HC_NUM + i] = uL * trL[i]; }  // :100
         return;
     } else if ((S_L <= 0.0) && (0.0 <= S_star)) {
         fv[Density] = rhoL * uL;
@@ -396,6 +403,10 @@ static void hllc_solve(const Real* L, const Real* R, Real* F) {
         svs[Eden] = coeff * (nrgL / rhoL + (S_star - uL) * (S_star + pL / (rhoL * (S_L - uL))));
 
         for (int i = 0; i < 5; ++i) { F[i] = fv[i] + S_L * (svs[i] - sv[i]); }
+        for (int i = 0; i < nt; ++i) {  // :111,120,131-137
+            Real fvt = uL * trL[i], svt = trL[i], svst = trL[i] * ((S_L - uL) / (S_L - S_star));
+            F[HC_NUM + i] = fvt + S_L * (svst - svt);
+        }
     } else if ((S_star <= 0.0) && (0.0 <= S_R)) {
         fv[Density] = rhoR * uR;
         fv[Xmom] = rhoR * uR * uR + pR;
@@ -418,17 +429,22 @@ static void hllc_solve(const Real* L, const Real* R, Real* F) {
         svs[Eden] = coeff * (nrgR / rhoR + (S_star - uR) * (S_star + pR / (rhoR * (S_R - uR))));
 
         for (int i = 0; i < 5; ++i) { F[i] = fv[i] + S_R * (svs[i] - sv[i]); }
+        for (int i = 0; i < nt; ++i) {  // :147,156,167-173
+            Real fvt = uR * trR[i], svt = trR[i], svst = trR[i] * ((S_R - uR) / (S_R - S_star));
+            F[HC_NUM + i] = fvt + S_R * (svst - svt);
+        }
     } else {
         F[Density] = rhoR * uR;
         F[Xmom] = rhoR * uR * uR + pR;
         F[Ymom] = rhoR * uR * vR;
         F[Zmom] = rhoR * uR * wR;
         F[Eden] = uR * (nrgR + pR);
+        for (int i = 0; i < nt; ++i) { F[HC_NUM + i] = trR[i] * uR; }  // :183
     }
 }
 
-// HydroHLLE::solve  hydro/riemann/MFP_hydro_hlle.cpp:30-120 (n_alpha = 0)
-static void hlle_solve(const Real* L, const Real* R, Real* F) {
+// HydroHLLE::solve  hydro/riemann/MFP_hydro_hlle.cpp:30-120; nt = n_alpha tracers
+static void hlle_solve(const Real* L, const Real* R, Real* F, int nt = 0) {
     Real rhoL = L[PDensity];
     Real uL = L[Xvel];
     Real vL = L[Yvel];
@@ -437,6 +453,8 @@ static void hlle_solve(const Real* L, const Real* R, Real* F) {
     Real gamL = L[Gamma];
     Real nrgL = pL / (gamL - 1) + 0.5 * rhoL * (uL * uL + vL * vL + wL * wL);
     Real aL = sqrt(gamL * pL / rhoL);
+    Real trL[CMFP_MAX_TRACERS], trR[CMFP_MAX_TRACERS];
+    for (int i = 0; i < nt; ++i) trL[i] = L[HP_NUM + i] * rhoL;  // :46-48
 
     Real rhoR = R[PDensity];
     Real uR = R[Xvel];
@@ -446,6 +464,7 @@ static void hlle_solve(const Real* L, const Real* R, Real* F) {
     Real gamR = R[Gamma];
     Real nrgR = pR / (gamR - 1) + 0.5 * rhoR * (uR * uR + vR * vR + wR * wR);
     Real aR = sqrt(gamR * pR / rhoR);
+    for (int i = 0; i < nt; ++i) trR[i] = R[HP_NUM + i] * rhoR;  // :60-62
 
     Real sL = std::min(uL - aL, uR - aR);
     Real sR = std::max(uL + aL, uR + aR);
@@ -456,6 +475,7 @@ static void hlle_solve(const Real* L, const Real* R, Real* F) {
         F[Ymom] = rhoL * uL * vL;
         F[Zmom] = rhoL * uL * wL;
         F[Eden] = uL * (nrgL + pL);
+        for (int i = 0; i < nt; ++i) { F[HC_NUM + i] = uL * trL[i]; }  // :75
     } else if ((sL <= 0.0) && (sR >= 0.0)) {
         Real fvL[5], fvR[5], svL[5], svR[5];
         fvL[Density] = rhoL * uL;
@@ -485,12 +505,17 @@ static void hlle_solve(const Real* L, const Real* R, Real* F) {
         for (int i = 0; i < 5; ++i) {
             F[i] = (sR * fvL[i] - sL * fvR[i] + sL * sR * (svR[i] - svL[i])) / (sR - sL);
         }
+        for (int i = 0; i < nt; ++i) {  // :83,91,99,107,109-111
+            Real fl = uL * trL[i], fr = uR * trR[i];
+            F[HC_NUM + i] = (sR * fl - sL * fr + sL * sR * (trR[i] - trL[i])) / (sR - sL);
+        }
     } else {
         F[Density] = rhoR * uR;
         F[Xmom] = rhoR * uR * uR + pR;
         F[Ymom] = rhoR * uR * vR;
         F[Zmom] = rhoR * uR * wR;
         F[Eden] = uR * (nrgR + pR);
+        for (int i = 0; i < nt; ++i) { F[HC_NUM + i] = uR * trR[i]; }  // :118
     }
 }
 
@@ -828,7 +853,7 @@ static void calc_reconstruction_generic(const StateDef& S, int DIM, const Box& b
     }
 }
 
-// HydroState::calc_reconstruction  hydro/MFP_hydro.cpp:780-1038 (no EB, no tracers)
+// HydroState::calc_reconstruction  hydro/MFP_hydro.cpp:780-1038 (no EB)
 static void calc_reconstruction_hydro(const StateDef& S, int DIM, const Box& box, Fab& prim,
                                       Fab* rlo, Fab* rhi) {
     const Box& pbox = prim.b;
@@ -839,7 +864,7 @@ static void calc_reconstruction_hydro(const StateDef& S, int DIM, const Box& box
     const int offset = sl / 2;
     Real stencil[7];
     int si[3];
-    Real Q[HP_NUM], cell_slope[HP_NUM];
+    Real Q[CMFP_MAX_COMP], cell_slope[CMFP_MAX_COMP];
     Real rho_lo, rho_hi, abs_phi, phi_scale, coeff_eps, gam_lo, gam_hi;
 
     for (int d = 0; d < DIM; ++d) {
@@ -921,6 +946,15 @@ static void calc_reconstruction_hydro(const StateDef& S, int DIM, const Box& box
 
                     lo4(i, j, k, Zvel) = w - 0.5 * (rho_hi / rho) * phi_w;
                     hi4(i, j, k, Zvel) = w + 0.5 * (rho_lo / rho) * phi_w;
+
+                    for (int n = 0; n < S.gas.nt; ++n) {  // :982-995
+                        Real& alpha = Q[HP_NUM + n];
+                        Real& phi_alpha = cell_slope[HP_NUM + n];
+                        Real alpha_lo = alpha - 0.5 * phi_alpha;
+                        Real alpha_hi = alpha + 0.5 * phi_alpha;
+                        lo4(i, j, k, HP_NUM + n) = alpha_lo;
+                        hi4(i, j, k, HP_NUM + n) = alpha_hi;
+                    }
 
                     gam_lo = S.gas.gamma;  // get_gamma_from_prim(alphas_lo, 0), gamma_const
                     gam_hi = S.gas.gamma;
@@ -1036,8 +1070,8 @@ static void st_riemann(const StateDef& S, Real c0, Real* L, Real* R, Real* F) {
         Real shk = 0.0;
         if (S.desc.shock_threshold > 0) shk = shock_detector(L, R, S.desc.shock_threshold);
         switch (S.desc.flux) {
-        case CMFP_FLUX_HLLC: hllc_solve(L, R, F); break;
-        case CMFP_FLUX_HLLE: hlle_solve(L, R, F); break;
+        case CMFP_FLUX_HLLC: hllc_solve(L, R, F, S.gas.nt); break;
+        case CMFP_FLUX_HLLE: hlle_solve(L, R, F, S.gas.nt); break;
         case CMFP_FLUX_HYBRID_HLL: hybrid_solve(L, R, F, shk); break;
         }
     } else {
@@ -1607,7 +1641,9 @@ struct Sim {
                             if (U[si][Density] < S.desc.effective_zero) {
                                 for (int l = 0; l < 8; ++l) Q[si][l] = 0.0;
                             } else {
-                                gas_cons2prim(S.gas, U[si], Q[si]);
+                                Gas g5 = S.gas;  // the collision terms use the five hydro components only
+                                g5.nt = 0;
+                                gas_cons2prim(g5, U[si], Q[si]);
                             }
                         }
                         for (int n = 0; n < n_species; ++n) {
@@ -1932,9 +1968,9 @@ static void setup_state(StateDef& S, const cmfp_state_desc& d, const cmfp_params
     S.num_grow = recon_num_grow(d.reconstruction);
     if (d.kind == CMFP_STATE_HYDRO && d.viscosity) S.num_grow = std::max(S.num_grow, 2);  // MFP_hydro.cpp:108-110
     if (d.kind == CMFP_STATE_HYDRO) {
-        S.gas = Gas{d.mass, d.charge, d.gamma};
-        S.n_cons = HC_NUM;
-        S.n_prim = HP_NUM;
+        S.gas = Gas{d.mass, d.charge, d.gamma, d.n_tracers};
+        S.n_cons = HC_NUM + d.n_tracers;  // MFP_hydro.H n_cons() / n_prim()
+        S.n_prim = HP_NUM + d.n_tracers;
         S.vec_prim[0] = Xvel;  // MFP_hydro.cpp:32-33
         S.vec_cons[0] = Xmom;
         S.n_vec = 1;

@@ -360,3 +360,61 @@ def test_reference_viscous_vortex_acceptance():
     sel = R <= 8.0
     rel = np.abs((vel[sel] - vt[sel]) / vt[sel])
     assert rel.max() <= 0.01, rel.max()
+
+
+# ---- passive scalars (tracers) ----------------------------------------------------------------
+def _band(d):
+    return (np.abs(d["y"] - 0.5) < 0.25).astype(float)
+
+
+@pytest.mark.parametrize("flux,scheme,recon", [("HLLC", "strang", "vanLeer"), ("HLLE", "strang", "minmod"),
+                                                ("HLLC", "RK2", "MC"), ("HLLC", "euler", "O6")])
+def test_tracers_parity_2d(oracle, flux, scheme, recon):
+    """hydro state with two passive scalars (stage-by-stage kernels): STRICT bit-identical to the
+    oracle, FAST within 1e-12, walls in y (scalar ghost rule on the tracer comps)."""
+    for walls in (False, True):
+        cfg = _kh(recon, flux, scheme)
+        if walls:
+            cfg["is_periodic"] = [1, 0]
+            wall = {"lo": {"fill_hydro_bc": "slipwall"}, "hi": {"fill_hydro_bc": "slipwall"}}
+            cfg["states"]["fluid"]["bc"] = {"y": wall}
+        problems.with_tracers(cfg, "fluid", [_band, lambda d: 0.25 + 0.5 * d["x"]])
+        for mode, tol in ((abi.FP_STRICT, 0.0), (abi.FP_FAST, 1e-12)):
+            P = config.Problem(cfg, fp_mode=mode)
+            ref = oracle.OracleSim(P)
+            dts_ref = ref.run(5)
+            m = _gpu(P)
+            dts = m.run(5)
+            assert m.last_advance_path() == 0
+            if tol == 0.0:
+                assert dts == dts_ref
+            assert rel_linf(m.download(0), ref.get_state(0)) <= tol, (walls, mode)
+            for c in (5, 6):
+                assert rel_linf(m.download(0)[c], ref.get_state(0)[c]) <= tol, (walls, mode, c)
+            m.close()
+
+
+def test_tracers_two_fluid_and_3d(oracle):
+    """tracers on the ion state of the two-fluid Orszag-Tang problem (plasma5 source beside them)
+    and on a 3-D two-fluid block: STRICT bit-identical to the oracle."""
+    cfg = problems.orszag_tang_two_fluid_2d(24)
+    problems.with_tracers(cfg, "ion", [lambda d: 0.5 + 0.25 * np.sin(d["x"])])
+    cfg3 = problems.richtmyer_meshkov_3d(16, 8, 8)
+    problems.with_tracers(cfg3, "electron", [lambda d: (d["x"] > 0).astype(float), 0.5])
+    for c in (cfg, cfg3):
+        P = config.Problem(c, fp_mode=abi.FP_STRICT)
+        ref = oracle.OracleSim(P)
+        ref.run(4)
+        m = _gpu(P)
+        m.run(4)
+        for s in range(m.n_states):
+            assert np.array_equal(m.download(s), ref.get_state(s)), (P.dim, P.state_names[s])
+        m.close()
+
+
+def test_tracers_with_hybrid_flux_are_refused():
+    cfg = _kh("minmod", "HLLE/HLLC", thr=0.3)
+    problems.with_tracers(cfg, "fluid", [0.5])
+    with pytest.raises(lib.CmfpError) as e:
+        _gpu(config.Problem(cfg))
+    assert e.value.code == abi.ERR_INVALID

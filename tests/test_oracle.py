@@ -223,3 +223,35 @@ def test_collisions_conserve_and_equilibrate(oracle, neutral):
     assert np.abs(ua - ub).max() < 1e-2 * np.abs(uT(U0[0])[0]).max()
     assert np.abs(Ta - Tb).max() < 2e-2 * Ta.max()
     assert Ta.min() > uT(U0[0])[1].max()          # the beam's drift energy became heat
+
+
+# ---- passive scalars (tracers) ------------------------------------------------------------
+def _kh_tracers(flux="HLLC", n=32):
+    cfg = problems.kelvin_helmholtz_2d(n, flux=flux, recon="vanLeer")
+    band = lambda d: (np.abs(d["y"] - 0.5) < 0.25).astype(float)
+    return problems.with_tracers(cfg, "fluid", [band, 1.0])
+
+
+@pytest.mark.parametrize("flux", ["HLLC", "HLLE"])
+def test_tracers_are_passive_conserved_and_keep_a_constant(oracle, flux):
+    """hydro state with two tracers (three species of equal mass / charge / gamma): the five hydro
+    components evolve exactly as without tracers, rho * alpha is conserved on the periodic domain,
+    alpha = 1 stays 1 (its flux is the mass flux), 0 <= alpha <= 1 for the band marker."""
+    P = config.Problem(_kh_tracers(flux))
+    assert P.n_comp(0) == 7 and P.state_descs()[0].n_tracers == 2
+    P0 = config.Problem(problems.kelvin_helmholtz_2d(32, flux=flux, recon="vanLeer"))
+    a, b = oracle.OracleSim(P), oracle.OracleSim(P0)
+    U0 = a.get_state(0).copy()
+    assert a.run(12) == b.run(12)
+    U, V = a.get_state(0), b.get_state(0)
+    assert np.array_equal(U[:5], V)
+    for c in (5, 6):
+        assert abs(U[c].sum() - U0[c].sum()) <= 1e-12 * np.abs(U0[c]).sum()
+    np.testing.assert_allclose(U[6] / U[0], 1.0, rtol=0, atol=1e-13)
+    al = U[5] / U[0]
+    assert al.min() > -1e-12 and al.max() < 1 + 1e-12
+    assert np.abs(al - U0[5] / U0[0]).max() > 1e-3        # and it did move
+    c, d = oracle.OracleSim(P), oracle.OracleSim(P, max_grid_size=8)
+    c.run(4)
+    d.run(4)
+    assert np.array_equal(c.get_state(0), d.get_state(0))
