@@ -42,8 +42,6 @@ def hydro_bc(bc_def, dim, periodic, n_tracers=0):
             name = _get(bc_def, d, side, "fill_hydro_bc", "outflow")  # MFP_hydro.cpp:342-345
             if name not in HYDRO_BC_NAMES:
                 raise ValueError(f"unknown fill_hydro_bc '{name}'")
-            if name == "inflow":
-                raise NotImplementedError("inflow (Lua Dirichlet) boundaries are outside the built path")
             t = 0 if periodic[d] else HYDRO_BC_NAMES[name]      # MFP_hydro.cpp:454-459
             out[0][d][side] = SCALAR_BC[t]
             out[4][d][side] = SCALAR_BC[t]
@@ -62,8 +60,6 @@ def field_bc(bc_def, dim, periodic):
         name = _get(bc_def, d, side, key, "outflow")             # MFP_field.cpp:323-326
         if name not in FIELD_BC_NAMES:
             raise ValueError(f"unknown {key} '{name}'")
-        if name == "inflow":
-            raise NotImplementedError("inflow (Lua Dirichlet) boundaries are outside the built path")
         return 0 if periodic[d] else FIELD_BC_NAMES[name]        # MFP_field.cpp:415-420
 
     for d in range(dim):
@@ -76,4 +72,52 @@ def field_bc(bc_def, dim, periodic):
             out[7][d][side] = SCALAR_BC[phys(d, side, "fill_psi_bc")]
             out[8][d][side] = SCALAR_BC[phys(d, side, "fill_mu_bc")]
             out[9][d][side] = SCALAR_BC[phys(d, side, "fill_ep_bc")]
+    return out
+
+
+HYDRO_PRIM_NAMES = ["rho", "x_vel", "y_vel", "z_vel", "p", "T", "gamma", "cp"]   # MFP_hydro.cpp:21-30
+FIELD_NAMES = ["x_D", "y_D", "z_D", "x_B", "y_B", "z_B", "phi", "psi", "mu", "ep"]
+
+
+def face_values(sd, dim, periodic, n_tracers=0):
+    """Per-face Dirichlet entries of a state definition: {(d, side): {carried primitive index: value}}
+    for every primitive name given a number or a function in states.<name>.bc.<dim>.<side>
+    (HydroState MFP_hydro.cpp:347-366, 383-409; FieldState MFP_field.cpp:340-352).  A face with at
+    least one entry is the reference's where_is_inflow = ext_dir (MFP_fillbc.cpp:72-87).
+    fill_hydro_bc = 'inflow' needs every primitive defined (:361-365)."""
+    out = {}
+    bc_def = sd.get("bc", {})
+    hydro = sd["type"] == "hydro"
+    for d in range(dim):
+        for side in range(2):
+            try:
+                face = bc_def[DIR_NAME[d]][SIDE_NAME[side]]
+            except (KeyError, TypeError):
+                continue
+            vals = {}
+            if hydro:
+                for n, name in enumerate(HYDRO_PRIM_NAMES):
+                    if name in face and n < 5:            # T, gamma, cp never reach the conserved result
+                        vals[n] = face[name]
+                    if face.get("fill_hydro_bc") == "inflow" and name not in face:
+                        raise ValueError("Setting 'fill_hydro_bc = inflow' requires all primitive variables to be "
+                                         f"defined, '{name}' is not defined")
+                alpha = face.get("alpha")
+                if alpha is not None:
+                    alpha = list(alpha) if isinstance(alpha, (list, tuple)) else [alpha] * n_tracers
+                    if len(alpha) < n_tracers:
+                        raise ValueError("Not enough boundary conditions specified for alpha")
+                    for i in range(n_tracers):
+                        vals[5 + i] = alpha[i]
+                elif face.get("fill_hydro_bc") == "inflow" and n_tracers:
+                    raise ValueError("Setting 'fill_hydro_bc = inflow' requires all primitive variables to be "
+                                     "defined, 'alpha' is not defined")
+            else:
+                for n, name in enumerate(FIELD_NAMES):
+                    if name in face:
+                        vals[n] = face[name]
+            if vals:
+                if periodic[d]:
+                    raise ValueError("boundary values given on a periodic face")
+                out[(d, side)] = vals
     return out

@@ -229,6 +229,51 @@ class Problem:
         sd = self.cfg["states"][self.state_names[s]]
         return 5 + gas_n_tracers(sd["gas"]) if sd["type"] == "hydro" else 10
 
+    # -- Dirichlet data of the domain faces ----------------------------------
+    def face_entries(self, s):
+        sd = self.cfg["states"][self.state_names[s]]
+        nt = gas_n_tracers(sd["gas"]) if sd["type"] == "hydro" else 0
+        return bc.face_values(sd, self.dim, self.periodic, nt)
+
+    def face_tables(self, s, ng, t, block_lo=None, block_n=None):
+        """Tabulated values of the per-face numbers / functions of (x, y, z, t) of state s:
+        [(d, side, prim, cell_values, face_values)] over the boxes cmfp_state_set_face_values
+        describes (block-local, ghost width ng).  Cell tables at the ghost-cell centres
+        (update_boundary_cells, MFP_eulerian.cpp:478-489), face tables at the face centres (offset 0
+        along the face normal, face_bc :841-855).  Only faces this block touches are returned."""
+        lo = [0, 0, 0] if block_lo is None else list(block_lo)
+        n = list(self.n_cell) if block_n is None else list(block_n)
+
+        def positions(d, side, face):
+            ax = []
+            for e in range(3):
+                if e >= self.dim:
+                    idx, off = np.zeros(1), 0.5
+                elif e != d:
+                    idx, off = np.arange(lo[e] - ng, lo[e] + n[e] + ng, dtype=np.float64), 0.5
+                elif face:
+                    idx, off = np.array([lo[e] if side == 0 else lo[e] + n[e]], dtype=np.float64), 0.0
+                else:
+                    a0 = lo[e] - ng if side == 0 else lo[e] + n[e]
+                    idx, off = np.arange(a0, a0 + ng, dtype=np.float64), 0.5
+                ax.append(self.prob_lo[e] + (idx + off) * self.dx[e])
+            z, y, x = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+            return {"x": x, "y": y, "z": z, "t": t}
+
+        out = []
+        for (d, side), vals in self.face_entries(s).items():
+            if (side == 0 and lo[d] != 0) or (side == 1 and lo[d] + n[d] != self.n_cell[d]):
+                continue
+            cdat, fdat = positions(d, side, False), positions(d, side, True)
+            for prim, v in vals.items():
+                cell = np.ascontiguousarray(self._eval(v, cdat, cdat["x"].shape))
+                face = np.ascontiguousarray(self._eval(v, fdat, fdat["x"].shape))
+                out.append((d, side, prim, cell, face))
+        return out
+
+    def face_values_depend_on_time(self, s):
+        return any(getattr(v, "uses_time", False) for vals in self.face_entries(s).values() for v in vals.values())
+
     # -- initial data ----------------------------------------------------
     def cell_centres(self, lo=None, n=None):
         lo = [0, 0, 0] if lo is None else list(lo) + [0] * (3 - len(lo))

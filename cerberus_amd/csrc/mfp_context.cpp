@@ -53,6 +53,10 @@ struct StateRT {
     double* rlo[3] = {nullptr, nullptr, nullptr};
     double* rhi[3] = {nullptr, nullptr, nullptr};
     double* flux[3] = {nullptr, nullptr, nullptr};
+    // Dirichlet data of the physical faces (cmfp_state_set_face_values): device tables [dim][side][prim]
+    double* tab_cell[3][2][CMFP_MAX_COMP] = {};
+    double* tab_face[3][2][CMFP_MAX_COMP] = {};
+    bool has_tables = false;
 };
 
 }  // namespace
@@ -356,6 +360,57 @@ int action_calc_time_derivative(cmfp_context* c, int ai, double dt) {
     return CMFP_OK;
 }
 
+// boxes of the Dirichlet tables of face (d, side) in block-local indices: ghost slab / face plane
+IBox table_box(const Geo& g, int d, int side, bool face) {
+    IBox b;
+    for (int e = 0; e < 3; ++e) {
+        b.lo[e] = -g.ng[e];
+        b.hi[e] = g.n[e] - 1 + g.ng[e];
+    }
+    if (face)
+        b.lo[d] = b.hi[d] = side == 0 ? 0 : g.n[d];
+    else if (side == 0)
+        b.hi[d] = -1;
+    else
+        b.lo[d] = g.n[d];
+    return b;
+}
+// EulerianState::update_boundary_cells (MFP_eulerian.cpp:435-511): ghost cells beyond the faces with
+// Dirichlet data, in the order of State::get_bc_limits (MFP_state.cpp:42-112)
+void apply_cell_tables(cmfp_context* c, StateRT& s) {
+    const Geo& g = c->g;
+    for (int d = 0; d < g.dim; ++d)
+        for (int side = 0; side < 2; ++side) {
+            if (!c->touches[d][side]) continue;
+            const IBox tb = table_box(g, d, side, false);
+            for (int n = 0; n < s.sp.nq; ++n)
+                if (s.tab_cell[d][side][n]) c->L->table_store(g, tb, tb, s.tab_cell[d][side][n], s.prim + n * g.sc, 0, c->stream);
+        }
+}
+// the Dirichlet part of face_bc (MFP_eulerian.cpp:838-877): outside face state = value at the face centre
+void apply_face_tables(cmfp_context* c, StateRT& s) {
+    const Geo& g = c->g;
+    const long str[3] = {1, g.sj, g.sk};
+    for (int d = 0; d < g.dim; ++d)
+        for (int side = 0; side < 2; ++side) {
+            if (!c->touches[d][side]) continue;
+            const IBox tb = table_box(g, d, side, true);
+            IBox pl;  // the face plane over the valid box (update_face_prim :901-953)
+            for (int e = 0; e < 3; ++e) {
+                pl.lo[e] = 0;
+                pl.hi[e] = g.n[e] - 1;
+            }
+            pl.lo[d] = pl.hi[d] = tb.lo[d];
+            for (int n = 0; n < s.sp.nq; ++n)
+                if (s.tab_face[d][side][n]) {
+                    if (side == 0)  // dest = L = r_hi of the ghost cell
+                        c->L->table_store(g, pl, tb, s.tab_face[d][side][n], s.rhi[d] + n * g.sc, -str[d], c->stream);
+                    else            // dest = R = r_lo of the ghost cell
+                        c->L->table_store(g, pl, tb, s.tab_face[d][side][n], s.rlo[d] + n * g.sc, 0, c->stream);
+                }
+        }
+}
+
 // HydroCTU::calc_spatial_derivative MFP_CTU_hydro.cpp:54-532, one kernel per stage
 int ctu_staged(cmfp_context* c, const cmfp_action_desc& A, double dt) {
     const Geo& g = c->g;
@@ -368,7 +423,9 @@ int ctu_staged(cmfp_context* c, const cmfp_action_desc& A, double dt) {
         Ptr3 rlo{{s.rlo[0], s.rlo[1], s.rlo[2]}}, rhi{{s.rhi[0], s.rhi[1], s.rhi[2]}};
         Ptr3 fl{{s.flux[0], s.flux[1], s.flux[2]}};
         c->L->prim(g, s.sp, s.U, s.prim, c->d_err, c->stream);                       // :182
+        if (s.has_tables) apply_cell_tables(c, s);                                   // :197
         c->L->recon(g, s.sp, s.prim, rlo, rhi, do_ctu, dt, c->stream);               // :212,230
+        if (s.has_tables) apply_face_tables(c, s);                                   // :281 (do_all = false)
         for (int d = 0; d < g.dim; ++d)                                              // :297
             c->L->fluxes(g, s.sp, d, s.rlo[d], s.rhi[d], s.flux[d], do_ctu, c->stream);
         if (g.dim > 1 && do_ctu) {
@@ -377,6 +434,7 @@ int ctu_staged(cmfp_context* c, const cmfp_action_desc& A, double dt) {
             for (int d = 0; d < g.dim; ++d)                                          // :328
                 for (int side = 0; side < 2; ++side)
                     if (c->touches[d][side]) c->L->face_bc(g, s.sp, d, side, s.rlo[d], s.rhi[d], c->stream);
+            if (s.has_tables) apply_face_tables(c, s);
             for (int d = 0; d < g.dim; ++d)                                          // :349
                 c->L->fluxes(g, s.sp, d, s.rlo[d], s.rhi[d], s.flux[d], do_ctu, c->stream);
         }
@@ -545,6 +603,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
                 const StatePhys& sp = c->states[A.states[i]].sp;
                 if (sp.kind == CMFP_STATE_HYDRO && sp.visc.kind) return 0;  // viscous fluxes: stage-by-stage kernels only
                 if (sp.kind == CMFP_STATE_HYDRO && sp.hp.nt) return 0;      // passive scalars: stage-by-stage kernels only
+                if (c->states[A.states[i]].has_tables) return 0;            // Dirichlet face data: stage-by-stage kernels only
                 if (c->fused != 2 && c->L->ctu_fused(c->g, sp, nullptr, nullptr, A.corner_transport, dt, c->touches, nullptr,
                                                      nullptr, 0 | tile_flag, c->stream)) {
                     tiled[A.states[i]] = 1;
@@ -1055,6 +1114,38 @@ int cmfp_est_time_step(cmfp_context* c, double* out) {
 double cmfp_compute_new_dt(double est_dt, double old_dt) {
     const double change_max = 1.1;  // MFP_timestep.cpp:89-92
     return std::min(est_dt, change_max * old_dt);
+}
+
+int cmfp_state_set_face_values(cmfp_context* c, int s, int dim, int side, int prim, const double* cell_values,
+                               const double* face_values) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (s < 0 || s >= (int)c->states.size() || dim < 0 || dim >= c->g.dim || side < 0 || side > 1)
+        return fail(c, CMFP_ERR_INVALID, "bad state / face");
+    StateRT& st = c->states[s];
+    if (prim < 0 || prim >= st.sp.nq) return fail(c, CMFP_ERR_INVALID, "bad primitive index");
+    if (c->geom.is_periodic[dim]) return fail(c, CMFP_ERR_INVALID, "Dirichlet data on a periodic face");
+    if ((cell_values == nullptr) != (face_values == nullptr)) return fail(c, CMFP_ERR_INVALID, "cell and face values go together");
+    if (!cell_values) {
+        // freed with the context (allocs); a removed entry is simply no longer applied
+        st.tab_cell[dim][side][prim] = st.tab_face[dim][side][prim] = nullptr;
+    } else {
+        const long nc = table_box(c->g, dim, side, false).npts(), nf = table_box(c->g, dim, side, true).npts();
+        double*& dc = st.tab_cell[dim][side][prim];
+        double*& df = st.tab_face[dim][side][prim];
+        if (!dc) {
+            if ((r = dalloc(c, &dc, nc))) return r;
+            if ((r = dalloc(c, &df, nf))) return r;
+        }
+        HIPCHK(c, hipMemcpyAsync(dc, cell_values, sizeof(double) * nc, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(df, face_values, sizeof(double) * nf, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffers may be reused on return
+    }
+    st.has_tables = false;
+    for (int d = 0; d < 3; ++d)
+        for (int sd = 0; sd < 2; ++sd)
+            for (int n = 0; n < CMFP_MAX_COMP; ++n) st.has_tables = st.has_tables || st.tab_cell[d][sd][n];
+    return CMFP_OK;
 }
 
 int cmfp_set_fused(cmfp_context* c, int enable) {

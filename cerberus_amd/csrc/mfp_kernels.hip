@@ -311,6 +311,16 @@ __global__ void k_correct(Geo g, IBox faces, int d1, HydroParams hp, double* __r
     }
 }
 
+// Dirichlet tables (EulerianState::update_boundary_cells MFP_eulerian.cpp:499-505, face_bc :866-872)
+__global__ void k_table_store(Geo g, IBox region, IBox tbox, const double* __restrict__ table, double* __restrict__ dst,
+                              long shift) {
+    int i, j, k;
+    if (!decode(region, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long lx = tbox.hi[0] - tbox.lo[0] + 1, ly = tbox.hi[1] - tbox.lo[1] + 1;
+    const long t = ((long)(k - tbox.lo[2]) * ly + (j - tbox.lo[1])) * lx + (i - tbox.lo[0]);
+    dst[g.at(i, j, k) + shift] = table[t];
+}
+
 // ------------------------------------------------------------ calc_divergence
 // EulerianState::calc_divergence MFP_eulerian.cpp:1614-1662
 __global__ void k_divergence(Geo g, IBox box, int nc, Ptr3 flux, double* __restrict__ dU, double dt) {
@@ -1124,6 +1134,12 @@ static void l_face_bc(const Geo& g, const StatePhys& sp, int d, int side, double
     LAUNCH(k_face_bc, pl.npts(), st, g, pl, d, side, sp.nq, face_rules(sp, d, side), rlo, rhi);
 }
 
+static void l_table_store(const Geo& g, const IBox& region, const IBox& tbox, const double* table, double* dst, long shift,
+                          hipStream_t st) {
+    if (region.npts() <= 0) return;
+    LAUNCH(k_table_store, region.npts(), st, g, region, tbox, table, dst, shift);
+}
+
 static void l_fluxes(const Geo& g, const StatePhys& sp, int d, const double* rlo, const double* rhi, double* flux,
                      int grown, hipStream_t st) {
     IBox fb = valid_box(g);
@@ -1349,7 +1365,7 @@ static void l_reduce_final(const double* part, int n, int is_max, unsigned long 
 const Launchers* launchers() {
     static const Launchers L = {l_prim,      l_recon,         l_face_bc,        l_fluxes,          l_correct,
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
-                                l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_fill_dim,        l_pack,
+                                l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack,
                                 ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
                                 l_leaf_prim2cons, l_reduce_final};
     return &L;

@@ -133,6 +133,9 @@ struct Launchers {
     void (*viscous)(const Geo&, const StatePhys&, int d, const double* U, double* flux, hipStream_t);
     // HydroViscous::get_min_dt cell loop: max over valid cells of calc_stability_condition
     void (*visc_stability)(const Geo&, const StatePhys&, const double* U, double* part, unsigned long long* out, hipStream_t);
+    // dst[cell + shift] = table[cell] over `region`; table laid out over the box tbox, i fastest
+    void (*table_store)(const Geo&, const IBox& region, const IBox& tbox, const double* table, double* dst, long shift,
+                        hipStream_t);
     // ghosts
     void (*fill_dim)(const Geo&, int nc, int ngs, double* A, int d, int side, FillRules, hipStream_t);
     void (*pack)(const Geo&, int nc, int ngs, double* A, int d, int side, double* buf, int unpack, hipStream_t);

@@ -71,6 +71,11 @@ class MFP:
         self._chk(self.L.cmfp_set_overlap(self.h, int(overlap)))
         self.shape = tuple(self.block_n[::-1])
         self.time, self.dt, self.step = 0.0, None, 0
+        self._time_bc = [s for s in range(self.n_states) if p.face_values_depend_on_time(s)]
+        if self._time_bc and p.scheme != "strang":
+            raise NotImplementedError("time-dependent boundary functions: 'strang' only (one flux evaluation at t + dt)")
+        for s in range(self.n_states):
+            self._upload_face_values(s, 0.0)
         self._cb = None
         self._bufs = {}
         self._exchange_device = exchange_device
@@ -138,8 +143,19 @@ class MFP:
         self._chk(self.L.cmfp_state_device_view(self.h, s, C.byref(ptr), C.byref(ng), C.byref(ext), C.byref(nc)))
         return ptr.value, ng.value, list(ext), nc.value
 
+    def _upload_face_values(self, s, t):
+        """bc.<dim>.<side>.<primitive> values / functions of (x, y, z, t), tabulated on this block."""
+        if not self.p.face_entries(s):
+            return
+        ng = self.device_view(s)[1]
+        for d, side, prim, cell, face in self.p.face_tables(s, ng, t, self.block_lo, self.block_n):
+            self._chk(self.L.cmfp_state_set_face_values(self.h, s, d, side, prim, cell.ctypes.data_as(lib.dp),
+                                                         face.ctypes.data_as(lib.dp)))
+
     # -- stepping ---------------------------------------------------------
     def advance(self, dt):
+        for s in self._time_bc:     # the flux stage of the Strang step is evaluated at time + dt (MFP_advance.cpp:208-217)
+            self._upload_face_values(s, self.time + dt)
         self._chk(self.L.cmfp_advance(self.h, self.time, dt))
         self.time += dt
         self.step += 1

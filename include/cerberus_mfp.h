@@ -199,6 +199,22 @@ int cmfp_state_download(cmfp_context* ctx, int state, double* host);
 int cmfp_state_device_view(cmfp_context* ctx, int state, double** dptr, int* ngrow,
                            long long extent[CMFP_MAX_DIM], int* ncomp);
 
+/* Dirichlet data of a physical domain face: the per-face values / functions of (x, y, z, t) the
+ * reference reads from states.<name>.bc.<dim>.<side>.<primitive> (BoundaryState::set,
+ * modules/boundary/MFP_fillbc.cpp:18-23; HydroState MFP_hydro.cpp:355-358, FieldState
+ * MFP_field.cpp:350), tabulated by the caller.  A face with data is the reference's
+ * where_is_inflow = ext_dir (:72-87): EulerianState::update_boundary_cells overwrites the primitive
+ * in the ghost cells beyond the face (MFP_eulerian.cpp:435-511) and face_bc sets the outside face
+ * state before each Riemann sweep (:838-877).  `prim` indexes the carried primitives: hydro
+ * {rho, x_vel, y_vel, z_vel, p, alpha_i}, field = conserved comps.  cell_values: the ghost layers
+ * beyond the face, i fastest, over the box that has the context's ghost width (cmfp_state_device_view)
+ * along `dim` and the block's ghosted extent in the other dimensions; face_values: one plane of the
+ * same transverse extent, at the face centres.  Host pointers; NULL, NULL removes the entry.
+ * Functions of the local state (the reference passes the interior primitives to the Lua function)
+ * are outside this interface.  States with Dirichlet data run on the stage-by-stage kernels. */
+int cmfp_state_set_face_values(cmfp_context* ctx, int state, int dim, int side, int prim,
+                               const double* cell_values, const double* face_values);
+
 /* ---- Action plugin API, one call per virtual of class Action
  * (actions/MFP_action.H:60-90).  They act on the context's UpdateData
  * {U, dU, status} per state (actions/MFP_action.H:16-29), owned by the

@@ -658,7 +658,36 @@ struct StateDef {
     Real div_speed, fastest_speed;  // field  (MFP_field.cpp:382-388)
     int vec_prim[2], vec_cons[2], n_vec;
     bool hydro() const { return desc.kind == CMFP_STATE_HYDRO; }
+    // Dirichlet data of the domain faces: the reference's per-face Lua values / functions of
+    // (x, y, z, t) (BoundaryState, modules/boundary/MFP_fillbc.cpp:8-88), tabulated by the caller.
+    // [dim][side][primitive]: values at the centres of the ghost cells beyond the face (box dbox:
+    // tng layers along dim, the other dimensions grown by tng) and at the face centres (box fbox).
+    struct FaceTab {
+        std::vector<Real> cell, face;
+    };
+    FaceTab tab[3][2][CMFP_MAX_COMP];
+    int tng = 0;
+    bool inflow(int d, int side) const {  // where_is_inflow == ext_dir  (:72-87)
+        for (int n = 0; n < CMFP_MAX_COMP; ++n)
+            if (!tab[d][side][n].cell.empty()) return true;
+        return false;
+    }
 };
+// boxes of the Dirichlet tables of face (d, side); linear index with i fastest
+static Box tab_box(const Box& domain, int DIM, int tng, int d, int side, bool face) {
+    Box b = grow(domain, tng, DIM);
+    if (face) {
+        b.lo[d] = b.hi[d] = side == 0 ? domain.lo[d] : domain.hi[d] + 1;
+    } else if (side == 0) {
+        b.hi[d] = domain.lo[d] - 1;
+    } else {
+        b.lo[d] = domain.hi[d] + 1;
+    }
+    return b;
+}
+static inline long tab_at(const Box& b, int i, int j, int k) {
+    return ((long)(k - b.lo[2]) * b.len(1) + (j - b.lo[1])) * b.len(0) + (i - b.lo[0]);
+}
 
 // HydroViscous family, hydro/viscous/MFP_hydro_viscous.cpp: get_coeffs (:145-160 Sutherland,
 // :207-220 PowerLaw, :266-279 UserDefined) and calc_stability_condition (:162-176, :222-236, :281-292)
@@ -822,6 +851,37 @@ static void calc_primitives(const StateDef& S, const Box& box, const Fab& cons, 
                 st_cons2prim(S, U, Q);
                 for (int n = 0; n < S.n_prim; ++n) prim(i, j, k, n) = Q[n];
             }
+}
+
+// EulerianState::update_boundary_cells  MFP_eulerian.cpp:435-511 with State::get_bc_limits
+// (MFP_state.cpp:17-116): in the ghost cells beyond a domain face that carries Dirichlet data, every
+// primitive that has a value there takes it (values tabulated at the ghost-cell centres)
+static void update_boundary_cells(const StateDef& S, int DIM, const Box& domain, const int* periodic, const Box& box, Fab& prim) {
+    bool all_periodic = true;
+    for (int d = 0; d < DIM; ++d) all_periodic = all_periodic && periodic[d];
+    if (all_periodic) return;  // :23
+    for (int d = 0; d < DIM; ++d) {
+        if (periodic[d]) continue;
+        for (int side = 0; side < 2; ++side) {
+            Box L = box;  // ghost slab of this box beyond the face  (:45-63)
+            if (side == 0) {
+                if (!(box.lo[d] < domain.lo[d])) continue;
+                L.hi[d] = domain.lo[d] - 1;
+            } else {
+                if (!(box.hi[d] > domain.hi[d])) continue;
+                L.lo[d] = domain.hi[d] + 1;
+            }
+            if (!S.inflow(d, side)) continue;  // :470-471
+            const Box tb = tab_box(domain, DIM, S.tng, d, side, false);
+            for (int n = 0; n < S.n_prim; ++n) {
+                const std::vector<Real>& t = S.tab[d][side][n].cell;
+                if (t.empty()) continue;  // f.is_valid()  :504
+                for (int k = L.lo[2]; k <= L.hi[2]; ++k)
+                    for (int j = L.lo[1]; j <= L.hi[1]; ++j)
+                        for (int i = L.lo[0]; i <= L.hi[0]; ++i) prim(i, j, k, n) = t[tab_at(tb, i, j, k)];
+            }
+        }
+    }
 }
 
 // EulerianState::calc_reconstruction  MFP_eulerian.cpp:513-607 (used by the field)
@@ -1014,14 +1074,13 @@ struct Geom {
     int periodic[3];
 };
 
-// EulerianState::update_face_prim + face_bc (do_all = true branch only; no
-// Lua inflow functions)  MFP_eulerian.cpp:882-955, 683-836.
+// EulerianState::update_face_prim + face_bc  MFP_eulerian.cpp:882-955, 683-880 (Dirichlet data
+// as tabulated values at the face centres).
 // At the low domain face the "L" state of the face plane (r_hi of the ghost
 // cell, shifted) is overwritten from the "R" state (r_lo of the first cell);
 // at the high face R (r_lo of the ghost cell) from L (r_hi of the last cell).
 static void update_face_prim(const StateDef& S, const Geom& G, const Box& box, Fab* r_lo, Fab* r_hi,
                              bool do_all) {
-    if (!do_all) return;  // only ext_dir inflow functions act when do_all = false (:840-877)
     for (int d = 0; d < G.DIM; ++d) {
         if (G.periodic[d]) continue;  // :899
         int e[3] = {0, 0, 0};
@@ -1035,7 +1094,7 @@ static void update_face_prim(const StateDef& S, const Geom& G, const Box& box, F
                 if (!(box.hi[d] >= G.domain.hi[d])) continue;  // :928
                 pl.lo[d] = pl.hi[d] = G.domain.hi[d] + 1;
             }
-            for (int n = 0; n < S.n_prim; ++n) {
+            for (int n = 0; n < S.n_prim && do_all; ++n) {
                 // fill_bc has n_prim entries but only the first n_cons are set
                 // (MFP_hydro.cpp:448-463); the rest stay BCType::bogus
                 int bc = (n < S.n_cons) ? S.desc.bc[n][d][side] : CMFP_BC_BOGUS;
@@ -1059,6 +1118,21 @@ static void update_face_prim(const StateDef& S, const Geom& G, const Box& box, F
                                 Real s = r_hi[d](i - e[0], j - e[1], k - e[2], n);
                                 r_lo[d](i, j, k, n) = (sgnv > 0) ? s : -s;
                             }
+                        }
+            }
+            if (!S.inflow(d, side)) continue;  // now do any dirichlet boundaries  :840-877
+            const Box tb = tab_box(G.domain, G.DIM, S.tng, d, side, true);
+            for (int n = 0; n < S.n_prim; ++n) {
+                const std::vector<Real>& t = S.tab[d][side][n].face;
+                if (t.empty()) continue;
+                for (int k = pl.lo[2]; k <= pl.hi[2]; ++k)
+                    for (int j = pl.lo[1]; j <= pl.hi[1]; ++j)
+                        for (int i = pl.lo[0]; i <= pl.hi[0]; ++i) {
+                            const Real v = t[tab_at(tb, i, j, k)];
+                            if (side == 0)
+                                r_hi[d](i - e[0], j - e[1], k - e[2], n) = v;  // dest = L
+                            else
+                                r_lo[d](i, j, k, n) = v;  // dest = R
                         }
             }
         }
@@ -1408,6 +1482,7 @@ struct Sim {
                 Fab R_lo[3], R_hi[3], fluxes[3];
                 const Box pbox = grow(box, S.num_grow, DIM);
                 calc_primitives(S, pbox, cons, prim);
+                update_boundary_cells(S, DIM, G.domain, G.periodic, pbox, prim);  // MFP_CTU_hydro.cpp:197
                 if (S.hydro())
                     calc_reconstruction_hydro(S, DIM, rbox, prim, R_lo, R_hi);
                 else
@@ -2123,6 +2198,17 @@ void* orc_create(const cmfp_geometry* g, const cmfp_params* p, int n_states, con
     return S;
 }
 void orc_destroy(void* h) { delete (Sim*)h; }
+// Dirichlet data of face (d, side) for primitive `prim` of state s (index into the reference's
+// primitive vector: hydro rho,x_vel,y_vel,z_vel,p,T,gamma,cp,alpha_i; field = conserved): values at the
+// ghost-cell centres (tab_box(.., false), tng ghost layers) and at the face centres (tab_box(.., true))
+void orc_set_face_values(void* h, int s, int d, int side, int prim, int tng, const double* cell, const double* face) {
+    Sim* S = (Sim*)h;
+    StateDef& st = S->states[s];
+    st.tng = tng;
+    const Box cb = tab_box(S->G.domain, S->G.DIM, tng, d, side, false), fb = tab_box(S->G.domain, S->G.DIM, tng, d, side, true);
+    st.tab[d][side][prim].cell.assign(cell, cell + cb.npts());
+    st.tab[d][side][prim].face.assign(face, face + fb.npts());
+}
 int orc_num_boxes(void* h) { return (int)((Sim*)h)->boxes.size(); }
 
 // host layout [comp][k][j][i] over the whole domain

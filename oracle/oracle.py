@@ -98,6 +98,20 @@ class OracleSim:
         self.shape = tuple(problem.n_cell[::-1])
         for s in range(len(problem.state_names)):
             self.set_state(s, problem.initial_data(s))
+        self.time = 0.0
+        self._time_bc = [s for s in range(len(problem.state_names)) if problem.face_values_depend_on_time(s)]
+        for s in range(len(problem.state_names)):
+            self._set_face_values(s, 0.0)
+
+    TNG = 4    # ghost width of the Dirichlet tables handed to the oracle (>= every num_grow)
+
+    def _set_face_values(self, s, t):
+        sd = self.p.cfg["states"][self.p.state_names[s]]
+        for d, side, prim, cell, face in self.p.face_tables(s, self.TNG, t):
+            # carried primitive index -> index in the reference's primitive vector (alpha behind the 8 hydro prims)
+            rp = prim if (sd["type"] != "hydro" or prim < 5) else prim + 3
+            lib().orc_set_face_values(self.h, C.c_int(s), C.c_int(d), C.c_int(side), C.c_int(rp), C.c_int(self.TNG),
+                                      _p(cell), _p(face))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -115,6 +129,9 @@ class OracleSim:
         return out
 
     def advance(self, dt):
+        for s in self._time_bc:
+            self._set_face_values(s, self.time + dt)
+        self.time += dt
         lib().orc_clear_error()
         lib().orc_advance(self.h, C.c_double(dt))
         if lib().orc_error_flag():

@@ -43,6 +43,10 @@ def _cfg(which):
         return problems.orszag_tang_two_fluid_2d(32)
     if which == "ot96":
         return problems.orszag_tang_two_fluid_2d(96)      # 48^2 blocks: interior tiles overlap the exchange
+    if which == "inflow":       # Dirichlet face tables cut into the ranks' blocks (stage-by-stage kernels)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_oracle import inflow_cfg
+        return inflow_cfg(32, 16)
     if which == "gem":
         return problems.gem_reconnection_2d(32, 32)
     return problems.richtmyer_meshkov_3d(16, 16, 16)     # 3-D: gather kernels, 1x2x2 blocks
@@ -57,7 +61,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,which,batched", [(2, "ot", True), (4, "ot", True), (4, "ot", False), (4, "gem", True), (4, "ot96", True), (2, "ot96", False),
-                                                 (4, "rmi3d", True)])
+                                                 (4, "rmi3d", True), (4, "inflow", True), (2, "inflow", False)])
 def test_decomposed_run_equals_single_rank(world, which, batched):
     import torch.multiprocessing as mp
     from cerberus_amd import abi, config, problems
@@ -80,7 +84,7 @@ def test_decomposed_run_equals_single_rank(world, which, batched):
     for r in range(world):
         o = ret[r]
         assert o["dts"] == dts
-        assert o["fused"]
+        assert o["fused"] == (which != "inflow")
         lo, n = o["lo"], o["n"]
         for s in range(len(full)):
             ref = full[s][:, lo[2]:lo[2] + n[2], lo[1]:lo[1] + n[1], lo[0]:lo[0] + n[0]]

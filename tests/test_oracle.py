@@ -255,3 +255,43 @@ def test_tracers_are_passive_conserved_and_keep_a_constant(oracle, flux):
     c.run(4)
     d.run(4)
     assert np.array_equal(c.get_state(0), d.get_state(0))
+
+
+# ---- Dirichlet (inflow) faces -----------------------------------------------------------------
+def inflow_cfg(n=48, ny=16, scheme="strang"):
+    """uniform supersonic stream entering at x-lo with a y-dependent density profile imposed through
+    bc.x.lo (fill_hydro_bc = 'inflow': every primitive given), leaving through an outflow at x-hi;
+    a moving slip wall in y with a prescribed tangential velocity value (the HartmannFlow input's
+    `y_vel = v_plate` on a wall face, here x_vel)."""
+    rho_in = lambda d: 1.0 + 0.2 * np.sin(2 * math.pi * d["y"])
+    inflow = {"fill_hydro_bc": "inflow", "rho": rho_in, "x_vel": 3.0, "y_vel": 0.0, "z_vel": 0.0, "p": 1.0,
+              "T": 1.0, "gamma": 1.4, "cp": 3.5}
+    cfg = problems.kelvin_helmholtz_2d(n, flux="HLLC", recon="vanLeer")
+    cfg.update({"n_cell": [n, ny], "prob_hi": [1.0, ny / n], "is_periodic": [0, 0], "time_integration_scheme": scheme})
+    st = cfg["states"]["fluid"]
+    st["value"] = {"rho": 1.0, "x_vel": 3.0, "y_vel": 0.0, "z_vel": 0.0, "p": 1.0}
+    st["bc"] = {"x": {"lo": inflow, "hi": {"fill_hydro_bc": "outflow"}},
+                "y": {"lo": {"fill_hydro_bc": "slipwall"}, "hi": {"fill_hydro_bc": "slipwall", "x_vel": 3.0}}}
+    return cfg
+
+
+def test_inflow_face_imposes_the_profile(oracle):
+    """supersonic inflow: after the stream has crossed a third of the domain the imposed density
+    profile has been carried in (first cells carry the face values), the far field is untouched"""
+    P = config.Problem(inflow_cfg())
+    sim = oracle.OracleSim(P)
+    t = 0.0
+    while t < 0.1:
+        dt = sim.est_time_step()
+        sim.advance(dt)
+        t += dt
+    U = sim.get_state(0)
+    y = P.prob_lo[1] + (np.arange(16) + 0.5) * P.dx[1]
+    prof = 1.0 + 0.2 * np.sin(2 * math.pi * y)
+    assert np.abs(U[0, 0, 2:-2, 0] - prof[2:-2]).max() < 2e-2          # the inflow column carries the profile
+    assert np.abs(U[0, 0, :, -4:] - 1.0).max() < 1e-12                 # nothing has reached the outflow yet
+    assert np.abs(U[0, 0, :, 10] - 1.0).max() > 0.05                   # the profile has moved in (x = 0.22 < 0.3)
+    with pytest.raises(ValueError):                                     # inflow needs every primitive (MFP_hydro.cpp:361-365)
+        cfg = inflow_cfg()
+        del cfg["states"]["fluid"]["bc"]["x"]["lo"]["p"]
+        config.Problem(cfg).face_entries(0)
