@@ -240,7 +240,7 @@ class Problem:
         [(d, side, prim, cell_values, face_values)] over the boxes cmfp_state_set_face_values
         describes (block-local, ghost width ng).  Cell tables at the ghost-cell centres
         (update_boundary_cells, MFP_eulerian.cpp:478-489), face tables at the face centres (offset 0
-        along the face normal, face_bc :841-855).  Only faces this block touches are returned."""
+        along the face normal, face_bc :841-855)."""
         lo = [0, 0, 0] if block_lo is None else list(block_lo)
         n = list(self.n_cell) if block_n is None else list(block_n)
 
@@ -262,8 +262,9 @@ class Problem:
 
         out = []
         for (d, side), vals in self.face_entries(s).items():
-            if (side == 0 and lo[d] != 0) or (side == 1 and lo[d] + n[d] != self.n_cell[d]):
-                continue
+            # every block registers every entry, also for faces it does not touch (the library applies a
+            # table only on a physical face of its block): the choice of kernel path then is the same
+            # on all ranks, which the halo exchange pattern relies on
             cdat, fdat = positions(d, side, False), positions(d, side, True)
             for prim, v in vals.items():
                 cell = np.ascontiguousarray(self._eval(v, cdat, cdat["x"].shape))

@@ -211,7 +211,9 @@ int cmfp_state_device_view(cmfp_context* ctx, int state, double** dptr, int* ngr
  * along `dim` and the block's ghosted extent in the other dimensions; face_values: one plane of the
  * same transverse extent, at the face centres.  Host pointers; NULL, NULL removes the entry.
  * Functions of the local state (the reference passes the interior primitives to the Lua function)
- * are outside this interface.  States with Dirichlet data run on the stage-by-stage kernels. */
+ * are outside this interface.  States with Dirichlet data run on the stage-by-stage kernels; where
+ * the domain is split between ranks every rank registers every entry (a table is applied only on a
+ * physical face of the rank's own block), so that all ranks take the same kernel path. */
 int cmfp_state_set_face_values(cmfp_context* ctx, int state, int dim, int side, int prim,
                                const double* cell_values, const double* face_values);
 
