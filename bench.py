@@ -97,11 +97,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ot2f_2d", choices=sorted(ALGO_BYTES))
-    ap.add_argument("--n", type=int, default=4096, help="cells per side of the per-GPU block")
+    ap.add_argument("--n", "--cells", dest="n", type=int, default=4096, help="cells per side of the per-GPU block")
     ap.add_argument("--fp", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--tiled-hydro", action="store_true", help="diagnostic: LDS-tiled hydro CTU kernel instead of the wave-marching one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="diagnostic: run the N-rank path on ONE GPU (all ranks on cuda:0, gloo with host-staged halos); not a measurement")
     ap.add_argument("--no-corner-transport", action="store_true", help="diagnostic: corner_transport=false (not the headline workload)")
     args = ap.parse_args()
 
@@ -117,10 +119,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hyperbolic update has no CPU fallback")
+    if args.rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     def hbm_copy_gbs():
         """attainable HBM bandwidth of this device: a 1 GiB device-to-device copy (read + write bytes)"""
@@ -140,7 +147,8 @@ def main():
     dim = 3 if args.workload == "rmi_3d" else 2
     grid = block_grid(dim, world)
     P = build_problem(args.workload, args.n, grid, fp_mode, not args.no_corner_transport)
-    m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=(3 if args.tiled_hydro else not args.no_fused))
+    m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=(3 if args.tiled_hydro else not args.no_fused),
+            exchange_device=("cpu" if args.rehearse and world > 1 else None))
     m.init_data()
 
     def sync():
@@ -162,7 +170,7 @@ def main():
     prof = [m.profile_read(s) for s in range(4)]
     m.profile_enable(False)
 
-    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    t = torch.tensor([el], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
