@@ -1116,6 +1116,84 @@ double cmfp_compute_new_dt(double est_dt, double old_dt) {
     return std::min(est_dt, change_max * old_dt);
 }
 
+// nsteps x {MFP::advance; MFP::computeNewDt} with dt kept on the device (no host round trip per step)
+int cmfp_advance_steps(cmfp_context* c, double, double dt0, int nsteps, double* dts, double* dt_next) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (nsteps < 1 || !dts || !dt_next) return fail(c, CMFP_ERR_INVALID, "bad arguments");
+    if (!c->fused) return 1;
+    for (int d = 0; d < c->g.dim; ++d)
+        if (c->split[d]) return 1;  // the cross-rank dt reduction needs the host: per-step API
+    const int ns = (int)c->states.size(), na = (int)c->actions.size();
+    DtPlan plan;
+    std::memset(&plan, 0, sizeof(plan));
+    plan.dim = c->g.dim;
+    for (int d = 0; d < 3; ++d) plan.dx[d] = c->g.dx[d];
+    plan.cfl = c->params.cfl;
+    if (ns + na > 24) return 1;
+    for (int s = 0; s < ns; ++s) {
+        if (state_viscous(c, s)) return 1;
+        const int n = plan.n++;
+        if (c->states[s].sp.kind == CMFP_STATE_HYDRO) {
+            plan.kind[n] = 0;
+            plan.word[n] = s;
+        } else {
+            plan.kind[n] = 1;
+            plan.cst[n] = state_dt_from(c, s, 0.0, 0.0);
+        }
+    }
+    for (int a = 0; a < na; ++a)
+        if (action_limits_dt(c->actions[a])) {
+            const int n = plan.n++;
+            plan.kind[n] = 2;
+            plan.word[n] = ns + a;
+            plan.cst[n] = action_dt_from(c, a, std::numeric_limits<double>::max());
+        }
+    double* d_dt = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_dt, sizeof(double) * (size_t)(nsteps + 1)));
+    double* d_log = d_dt + 1;
+    auto cleanup = [&]() {
+        c->g.dtp = nullptr;
+        (void)hipFree(d_dt);
+    };
+    hipError_t e = hipMemcpyAsync(d_dt, &dt0, sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(c, CMFP_ERR_HIP, hipGetErrorString(e));
+    }
+    c->g.dtp = d_dt;
+    for (int i = 0; i < nsteps; ++i) {
+        std::fill(c->red_valid.begin(), c->red_valid.end(), 0);
+        r = advance_strang_fused(c, 1.0);  // dt arguments become factors of *dtp
+        if (r <= 0) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            cleanup();
+            if (r < 0) return r;
+            if (i == 0) return 1;  // configuration outside the fused kernels: nothing was advanced
+            return fail(c, CMFP_ERR_INVALID, "fused path became unavailable between steps");
+        }
+        c->last_fused = r;
+        for (int s = 0; s < ns; ++s)
+            if (c->states[s].sp.kind == CMFP_STATE_HYDRO && !c->red_valid[s]) {
+                launch_state_dt(c, s, s);
+                c->red_valid[s] = 1;
+            }
+        for (int a = 0; a < na; ++a)
+            if (action_limits_dt(c->actions[a]) && !c->red_valid[ns + a]) {
+                launch_action_dt(c, a, ns + a);
+                c->red_valid[ns + a] = 1;
+            }
+        c->L->new_dt(plan, c->d_red, d_dt, d_log, i, c->stream);
+    }
+    c->g.dtp = nullptr;
+    e = hipMemcpyAsync(dts, d_log, sizeof(double) * (size_t)nsteps, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dt_next, d_dt, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    r = sync_and_check(c);
+    (void)hipFree(d_dt);
+    if (e != hipSuccess) return fail(c, CMFP_ERR_HIP, hipGetErrorString(e));
+    return r;
+}
+
 int cmfp_state_set_face_values(cmfp_context* c, int s, int dim, int side, int prim, const double* cell_values,
                                const double* face_values) {
     int r;

@@ -67,6 +67,21 @@ CMFP_DEV double f_rcp(double x) { return 1 / x; }
 CMFP_DEV double f_div(double a, double b) { return a / b; }
 CMFP_DEV double f_sqrt(double x) { return sqrt(x); }
 #endif
+// Time step of a launch: the `dt` argument, or, with a device-resident time step (Geo::dtp,
+// cmfp_advance_steps), that argument as a factor of *dtp.  The product is wave-uniform; it is moved
+// to scalar registers so that it costs no vector registers (the tiled field kernel sits exactly at
+// its 168-VGPR budget).
+// a wave-uniform value moved to scalar registers
+CMFP_DEV double uni(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+CMFP_DEV double launch_dt(const cmfp::Geo& g, double dt) {
+    if (!g.dtp) return dt;
+    return uni(dt * *g.dtp);
+}
+
 // std::min / std::max semantics (return the first argument on ties / NaN)
 CMFP_DEV double std_min(double a, double b) { return (b < a) ? b : a; }
 CMFP_DEV double std_max(double a, double b) { return (a < b) ? b : a; }

@@ -89,6 +89,10 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
     constexpr int NQ = Phys::NQ, NC = Phys::NC, NF = Phys::NF, RECON = Phys::RECON;
     constexpr int SL = ReconTraits<RECON>::SL, H = SL / 2;
     constexpr int TX = BX - 2, TY = BY - 2;
+    dt = launch_dt(g, dt);  // device-resident time step (cmfp_advance_steps)
+    // wave-uniform factors, held in scalar registers (the field kernel sits at its VGPR budget)
+    const double h_dx[2] = {uni(0.5 * dt / g.dx[0]), uni(0.5 * dt / g.dx[1])};
+    const double dt_dx[2] = {uni(dt / g.dx[0]), uni(dt / g.dx[1])};
     constexpr int PX = BX + 2 * H, PY = BY + 2 * H;
     constexpr int C = BX * BY;
     static_assert(BX == 16, "the x-neighbour exchange uses DPP shifts inside rows of 16 lanes");
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
                     for (int n = 0; n < 5; ++n) st[s][n] = Pq[n * (PX * PY) + pc + (s - H) * sd];
                 hydro_cell_faces<RECON>(Phys::gamma_of(P), st, lo[d], hi[d]);
                 if (do_ctu) {
-                    const double dt_2dx = 0.5 * dt / g.dx[d];
+                    const double dt_2dx = h_dx[d];
 #pragma unroll
                     for (int n = 0; n < NQ; ++n) trace_faces(speed[d], dt_2dx, centre[n], lo[d][n], hi[d][n]);
                 }
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
                 const int sd = d == 0 ? 1 : PX;
-                const double dt_2dx = 0.5 * dt / g.dx[d];
+                const double dt_2dx = h_dx[d];
 #pragma unroll
                 for (int m = 0; m < NH; ++m) {
                     const int n = h0 + m;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
         if (row_in) {
             // x-face states use F_y(i,j) - F_y(i,j+1)
             double dF[NF];
-            const double k = 0.5 * dt / g.dx[1];
+            const double k = h_dx[1];
 #pragma unroll
             for (int n = 0; n < NF; ++n) dF[n] = fy[n] - Fb[n * C + tid + BX];
             if (tx <= BX - 2 && i < n0) {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
         }
         if (col_in) {
             double dF[NF];
-            const double k = 0.5 * dt / g.dx[0];
+            const double k = h_dx[0];
 #pragma unroll
             for (int n = 0; n < NF; ++n) dF[n] = fx[n] - fxr[n];
             if (ty <= BY - 2 && j < n1) {
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
     // ---- phase 5: divergence (calc_divergence MFP_eulerian.cpp:1614-1662) and new += dU
     if (tx >= 1 && tx <= BX - 2 && ty >= 1 && ty <= BY - 2 && i < n0 && j < n1) {
         const long c = g.at(i, j, 0);
-        const double dtdx = dt / g.dx[0], dtdy = dt / g.dx[1];
+        const double dtdx = dt_dx[0], dtdy = dt_dx[1];
         double Unew[NC];
 #pragma unroll
         for (int n = 0; n < NC; ++n) {

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(GT) void k_g_flux(Geo g, GBox box, typename Phys::P
                                                 Ptr3 F1, Ptr3 F2, int do_ctu, double dt, FaceBC3 bc, int* err) {
     int idx[3];
     if (!g_cell(box, idx[0], idx[1], idx[2])) return;
+    dt = launch_dt(g, dt);  // device-resident time step (cmfp_advance_steps)
     const long c = g.at(idx[0], idx[1], idx[2]);
     g_flux_dir<Phys, DIM, SWEEP2, 0>(g, P, U, F1, F2, do_ctu, dt, bc, err, idx, c);
     if constexpr (DIM > 1) g_flux_dir<Phys, DIM, SWEEP2, 1>(g, P, U, F1, F2, do_ctu, dt, bc, err, idx, c);
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(GT) void k_g_update(Geo g, GBox box, GasP gas, cons
                                                   double* __restrict__ Uout, Ptr3 F, double dt, unsigned long long* red) {
     int i = 0, j = 0, k = 0;
     const bool on = g_cell(box, i, j, k);
+    dt = launch_dt(g, dt);  // device-resident time step (cmfp_advance_steps)
     double red_speed = 2.2250738585072014e-308;
     if (on) {
         const long str[3] = {1, g.sj, g.sk};

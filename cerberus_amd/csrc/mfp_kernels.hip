@@ -372,7 +372,7 @@ __global__ void k_lincomb(Geo g, IBox box, int nc, double* dst, double a, const 
 struct SourceCoef {
     double f1, f2, f3;
 };
-static SourceCoef source_coef(const SourceArgs& a, double dt) {
+__host__ __device__ static inline SourceCoef source_coef(const SourceArgs& a, double dt) {
     // MFP_plasma5.cpp:123-129
     const double c_h = a.c_h;
     const double c_d = a.div_damp != 0.0 ? c_h / a.div_damp : 0.0;
@@ -718,6 +718,10 @@ __device__ __forceinline__ void st_plane(double* base, unsigned off, double v) {
 
 template <int NS, bool IMPL, bool REDUCE, bool COLL>
 __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs a, SourceCoef kf, double dt) {
+    if (g.dtp) {  // device-resident time step (cmfp_advance_steps): dt is the factor 1/2 of the half step
+        dt = launch_dt(g, dt);
+        kf = source_coef(a, dt);
+    }
     const long npts = box.npts();
     double red_speed[NS];
     double red_dt = DBL_MAX;
@@ -1358,6 +1362,35 @@ static int l_ctu_gather(const Geo& g, const StatePhys& sp, const double* Uin, do
     if (g.dim == 2) return ctu_gather_2(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);
     return ctu_gather_3(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);
 }
+// MFP::estTimeStep (MFP_timestep.cpp:4-21: cfl * min over states and actions) and the growth cap of
+// MFP::computeNewDt (:86-93) on the device; the same expressions as the host path of
+// cmfp_est_time_step / cmfp_compute_new_dt
+__global__ void k_new_dt(DtPlan p, const unsigned long long* __restrict__ red, double* __restrict__ dt, double* __restrict__ log,
+                         int idx) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double est = DBL_MAX;
+    for (int n = 0; n < p.n; ++n) {
+        double d;
+        if (p.kind[n] == 0) {  // EulerianState::get_allowed_time_step MFP_eulerian.cpp:302-303
+            const double sp = __longlong_as_double((long long)red[p.word[n]]);
+            d = p.dx[0] / sp;
+            for (int i = 1; i < p.dim; ++i) d = std_min(d, p.dx[i] / sp);
+        } else if (p.kind[n] == 1) {
+            d = p.cst[n];
+        } else {  // Plasma5::get_allowed_time_step MFP_plasma5.cpp:457-567
+            d = std_min(p.cst[n], __longlong_as_double((long long)red[p.word[n]]));
+        }
+        est = std_min(est, d);
+    }
+    est *= p.cfl;
+    const double old = dt[0];
+    log[idx] = old;
+    dt[0] = std_min(est, 1.1 * old);
+}
+static void l_new_dt(const DtPlan& p, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t st) {
+    hipLaunchKernelGGL(k_new_dt, dim3(1), dim3(64), 0, st, p, red, dt, log, idx);
+}
+
 static void l_reduce_final(const double* part, int n, int is_max, unsigned long long* out, hipStream_t st) {
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, part, n, is_max, out);
 }
@@ -1367,7 +1400,7 @@ const Launchers* launchers() {
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack,
                                 ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
-                                l_leaf_prim2cons, l_reduce_final};
+                                l_leaf_prim2cons, l_reduce_final, l_new_dt};
     return &L;
 }
 

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, typename Phys::Param
                                                       unsigned long long* red) {
     constexpr int RECON = Phys::RECON;
     static_assert(ReconTraits<RECON>::SL == 3 && Phys::IS_HYDRO, "three-point hydro reconstructions");
+    dt = launch_dt(g, dt);  // device-resident time step (cmfp_advance_steps)
     const int lane = threadIdx.x;
     // XCD-aware order (see mfp_fused.hip): neighbouring strips, which share stencil columns, run on one XCD
     const int per = (sel.nwaves + 7) >> 3;
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, typename Phys::Param
     const bool inner = lane >= 2 && lane <= 61;
     const bool upd = inner && i <= R.ihi;
     const double gamma = Phys::gamma_of(P), gm1 = gamma - 1.0;
-    const double kx = 0.5 * dt / g.dx[0], ky = 0.5 * dt / g.dx[1];
-    const double dtdx = dt / g.dx[0], dtdy = dt / g.dx[1];
+    const double kx = uni(0.5 * dt / g.dx[0]), ky = uni(0.5 * dt / g.dx[1]);  // wave-uniform: scalar registers
+    const double dtdx = uni(dt / g.dx[0]), dtdy = uni(dt / g.dx[1]);
     const long col = g.at(ic, 0, 0);
     bool bad = false;
 

@@ -28,6 +28,10 @@ struct Geo {
     int ext[3];  // n + 2 ng
     long sj, sk, sc;
     double dx[3];
+    // device-resident time step (cmfp_advance_steps): when set, a kernel's `dt` argument is a factor
+    // (1 for the flux update, 1/2 for a source half step) of *dtp, read on the device, so that a
+    // sequence of steps can be enqueued without the host knowing dt
+    const double* dtp;
     __host__ __device__ long at(int i, int j, int k) const {
         return (long)(i + ng[0]) + (long)(j + ng[1]) * sj + (long)(k + ng[2]) * sk;
     }
@@ -106,6 +110,17 @@ struct FillRules {
     int rule[10];
 };
 
+// What MFP::estTimeStep combines (MFP_timestep.cpp:4-21), for the device-side step control
+struct DtPlan {
+    int n;
+    int kind[24];    // 0: hydro state (word = max speed), 1: constant (field state), 2: action (min(cst, word))
+    int word[24];
+    double cst[24];
+    int dim;
+    double dx[3];
+    double cfl;
+};
+
 // Host-side launchers of one floating-point mode (namespace strict / fast).
 struct Launchers {
     // staged kernels: one per FAB-level function of the reference
@@ -155,6 +170,8 @@ struct Launchers {
     int (*leaf_cons2prim)(long n, double mass, double gamma, const double* U, double* Q, double* sp, hipStream_t);
     int (*leaf_prim2cons)(long n, double mass, double gamma, const double* Q, double* U, hipStream_t);
     void (*reduce_final)(const double* part, int n, int is_max, unsigned long long* out, hipStream_t);
+    // MFP::estTimeStep + computeNewDt on the device: log[idx] = dt[0]; dt[0] = min(cfl * est, 1.1 * dt[0])
+    void (*new_dt)(const DtPlan&, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t);
 };
 
 }  // namespace cmfp

@@ -41,7 +41,7 @@ def coords_rank(c, grid):
 
 class MFP:
     def __init__(self, problem, device=0, rank=0, world=1, stream=0, fused=True, pg=None, exchange_device=None,
-                 batched_exchange=True, overlap=1):
+                 batched_exchange=True, overlap=1, device_dt=True):
         self.L = lib.load()
         self.p = problem if isinstance(problem, Problem) else Problem(problem)
         p = self.p
@@ -71,6 +71,7 @@ class MFP:
         self._chk(self.L.cmfp_set_overlap(self.h, int(overlap)))
         self.shape = tuple(self.block_n[::-1])
         self.time, self.dt, self.step = 0.0, None, 0
+        self._device_dt = bool(device_dt) and world == 1
         self._time_bc = [s for s in range(self.n_states) if p.face_values_depend_on_time(s)]
         if self._time_bc and p.scheme != "strang":
             raise NotImplementedError("time-dependent boundary functions: 'strang' only (one flux evaluation at t + dt)")
@@ -189,6 +190,19 @@ class MFP:
         dts = []
         if self.dt is None:
             self.dt = self.est_time_step() if dt0 is None else dt0
+        if self._device_dt and nsteps > 0 and not self._time_bc:
+            # the whole loop on the device (cmfp_advance_steps): no host round trip per step
+            out, nxt = np.empty(nsteps), C.c_double()
+            rc = self.L.cmfp_advance_steps(self.h, self.time, self.dt, nsteps, out.ctypes.data_as(lib.dp), C.byref(nxt))
+            if rc == 0:
+                for v in out:
+                    self.time += float(v)
+                self.step += nsteps
+                self.dt = nxt.value
+                return [float(v) for v in out]
+            if rc != 1:
+                self._chk(rc)
+            self._device_dt = False      # not applicable to this configuration: per-step calls
         for _ in range(nsteps):
             self.advance(self.dt)
             dts.append(self.dt)

@@ -251,6 +251,16 @@ int cmfp_update_download(cmfp_context* ctx, int state, int which /*0=U,1=dU*/, d
 int cmfp_est_time_step(cmfp_context* ctx, double* dt);
 double cmfp_compute_new_dt(double est_dt, double old_dt);
 int cmfp_advance(cmfp_context* ctx, double time, double dt);
+/* nsteps iterations of the loop around it — Amr::coarseTimeStep -> MFP::advance, then
+ * MFP::computeNewDt = min(cfl * estTimeStep, 1.1 * dt) (main.cpp:154-162, MFP_timestep.cpp:4-21,61-93;
+ * no stop_time clip) — with dt resident on the device: every kernel reads it there and a one-thread
+ * kernel applies estTimeStep / computeNewDt after each step, so nsteps steps are enqueued without a
+ * host round trip (per-step launch + read-back latency is what bounds small grids).  dt0: the first
+ * step's dt; dts[0..nsteps): the dt each step used; dt_next: the one computeNewDt leaves for the
+ * next step.  Same arithmetic as cmfp_est_time_step / cmfp_compute_new_dt: STRICT results are
+ * bit-identical to the per-step calls.  Returns 1 without advancing where it does not apply (stage-by-stage
+ * path, viscous states, a block split between ranks: the cross-rank dt reduction is the caller's). */
+int cmfp_advance_steps(cmfp_context* ctx, double time, double dt0, int nsteps, double* dts, double* dt_next);
 /* Uses hand-fused kernels inside cmfp_advance where available (default 1: the
  * LDS-tiled kernel for 2-D blocks, the tile-free gather kernels for 1-D and 3-D);
  * 2 forces the gather kernels in any dimensionality; 0 forces the stage-by-stage

@@ -66,3 +66,21 @@ def test_split_launches_identical(oracle, case, fused):
     for s in range(m.n_states):
         assert np.array_equal(m.download(s), ref.get_state(s)), (name, P.state_names[s])
     m.close()
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_device_resident_dt_equals_per_step_calls(case):
+    """cmfp_advance_steps (dt kept on the device, estTimeStep + computeNewDt in a kernel) against the
+    per-step cmfp_advance / cmfp_est_time_step / cmfp_compute_new_dt loop: identical dt sequence and
+    identical states (STRICT), in 1-D, 2-D and 3-D, also when called twice in a row."""
+    name, cfg, steps = small_cases()[case]
+    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    a, b = _gpu(P, device_dt=True), _gpu(P, device_dt=False)
+    da = a.run(3) + a.run(steps)
+    db = b.run(3) + b.run(steps)
+    assert a._device_dt and not b._device_dt
+    assert da == db and a.dt == b.dt and a.time == b.time and a.step == b.step
+    for s in range(a.n_states):
+        assert np.array_equal(a.download(s), b.download(s)), (name, P.state_names[s])
+    a.close()
+    b.close()
