@@ -445,12 +445,17 @@ extern "C" void cmfp_debug_stamps(unsigned long long* out, int reset) {
 int ctu_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
               const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st);
 
+int ctu_march3d(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
+                const int touches[3][2], int* err, unsigned long long* red, hipStream_t st);
+
 // part bit 8 set: the LDS-tiled kernel even where the wave-marching kernel (mfp_march.hip) applies
 int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
               const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st) {
-    if (g.dim != 2) return 0;
     const bool tile_only = part & 0x100;
     part &= 0xff;
+    if (g.dim == 3)  // z-marching kernel (mfp_march3d.hip): whole block in one launch
+        return (tile_only || part != 0) ? 0 : ctu_march3d(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, st);
+    if (g.dim != 2) return 0;
     if (!tile_only && ctu_march(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, part, st)) return 1;
 #define HY(R, F)                                                                                                    \
     if (sp.recon == R && sp.flux == F)                                                                              \
