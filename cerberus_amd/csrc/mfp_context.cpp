@@ -594,7 +594,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     }
     // probe coverage (null launches): the tiled 2-D kernel where it applies, else the gather kernels
     const int tile_flag = c->fused == 3 ? 0x100 : 0;  // 3: the LDS-tiled kernel also where the wave-marching one applies
-    std::vector<char> tiled(c->states.size(), 0);
+    std::vector<char> tiled(c->states.size(), 0), f3d(c->states.size(), 0);
     bool any_gather = false;
     const Ptr3 none{{nullptr, nullptr, nullptr}};
     for (const auto& A : c->actions)
@@ -607,6 +607,10 @@ int advance_strang_fused(cmfp_context* c, double dt) {
                 if (c->fused != 2 && c->L->ctu_fused(c->g, sp, nullptr, nullptr, A.corner_transport, dt, c->touches, nullptr,
                                                      nullptr, 0 | tile_flag, c->stream)) {
                     tiled[A.states[i]] = 1;
+                } else if (c->fused == 1 && c->L->ctu_field3d(c->g, sp, nullptr, nullptr, none, A.corner_transport, dt, c->touches,
+                                                              c->stream)) {
+                    f3d[A.states[i]] = 1;  // 3-D field: two-pass z-marching kernels (they use the F1 scratch)
+                    any_gather = true;
                 } else if (c->L->ctu_gather(c->g, sp, nullptr, nullptr, none, none, A.corner_transport, dt, c->touches,
                                             nullptr, nullptr, c->stream)) {
                     any_gather = true;
@@ -690,6 +694,8 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         if (tiled[list[q]])
             c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], (overlap ? 2 : 0) | tile_flag,
                             c->stream);
+        else if (f3d[list[q]])
+            c->L->ctu_field3d(c->g, s.sp, s.new_data, s.alt, F1, ctu_flag[q], dt, c->touches, c->stream);
         else
             c->L->ctu_gather(c->g, s.sp, s.new_data, s.alt, F1, F2, ctu_flag[q], dt, c->touches, c->d_err, slots[q], c->stream);
     }

@@ -1356,6 +1356,9 @@ int ctu_fused(const Geo&, const StatePhys&, const double* Uin, double* Uout, int
                        int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
 CMFP_GATHER_DECL(1) CMFP_GATHER_DECL(2) CMFP_GATHER_DECL(3)
 #undef CMFP_GATHER_DECL
+// defined in mfp_field3d.hip
+int ctu_field3d(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, int do_ctu, double dt,
+                const int touches[3][2], hipStream_t);
 static int l_ctu_gather(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
                         int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
     if (g.dim == 1) return ctu_gather_1(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);
@@ -1399,7 +1402,7 @@ const Launchers* launchers() {
     static const Launchers L = {l_prim,      l_recon,         l_face_bc,        l_fluxes,          l_correct,
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack,
-                                ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
+                                ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
                                 l_leaf_prim2cons, l_reduce_final, l_new_dt};
     return &L;
 }

@@ -163,6 +163,9 @@ struct Launchers {
     // tile-free fused CTU update for any dimensionality (mfp_gather.hip); F1 / F2: face-flux scratch, 8 planes per direction
     int (*ctu_gather)(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
                       int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
+    // two-pass z-marching update of a 3-D field state (mfp_field3d.hip); F1: sweep-1 flux scratch
+    int (*ctu_field3d)(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, int do_ctu, double dt,
+                       const int touches[3][2], hipStream_t);
     // batched leaves
     int (*leaf_reconstruct)(int recon, long n, const double* st, double* slope, double* lo, double* hi, hipStream_t);
     int (*leaf_riemann)(int flux, long n, const double* L, const double* R, double* F, double c0, double ch,
