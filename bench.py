@@ -199,7 +199,7 @@ def main():
             kname = ("k_ctu2d<HydroF<minmod,HLLC>> (LDS-tiled" if args.tiled_hydro or dim != 2 else
                      "k_ctu_march<HydroF<minmod,HLLC>> (wave-marching") + " fused CTU update of one hydro state)"
             if dim == 3:
-                kname = "k_g_flux/k_g_update<HydroF<minmod,HLLC>> (gather kernels, fused CTU update of one hydro state)"
+                kname = "k_ctu3d<HydroF<minmod,HLLC>> (z-marching fused CTU update of one hydro state)"
             roof = {"bound": "hbm", "kernel": kname,
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "attainable_copy_GBs": copy_gbs, "frac_of_attainable": achieved / copy_gbs,

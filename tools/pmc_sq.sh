@@ -13,6 +13,6 @@ for r in csv.DictReader(open(f)):
     k=r["Kernel_Name"][:70]; acc[k][r["Counter_Name"]]+=float(r["Counter_Value"])
     if r["Counter_Name"]=="SQ_WAVES": cnt[k]+=1
 for k,v in acc.items():
-    if "ctu" in k or "source" in k or "g_flux" in k or "march" in k:
+    if "ctu" in k or "source" in k or "g_flux" in k or "march" in k or "f3d" in k:
         w=v["SQ_WAVES"]; print(k, "launches",cnt[k], {n:round(x/w,1) for n,x in v.items() if n!="SQ_WAVES"}, "waves/launch", w/cnt[k])
 PY
