@@ -607,9 +607,9 @@ int advance_strang_fused(cmfp_context* c, double dt) {
                 if (c->fused != 2 && c->L->ctu_fused(c->g, sp, nullptr, nullptr, A.corner_transport, dt, c->touches, nullptr,
                                                      nullptr, 0 | tile_flag, c->stream)) {
                     tiled[A.states[i]] = 1;
-                } else if (c->fused == 1 && c->L->ctu_field3d(c->g, sp, nullptr, nullptr, none, A.corner_transport, dt, c->touches,
+                } else if (c->fused == 1 && c->L->ctu_field3d(c->g, sp, nullptr, nullptr, none, nullptr, A.corner_transport, dt, c->touches,
                                                               c->stream)) {
-                    f3d[A.states[i]] = 1;  // 3-D field: two-pass z-marching kernels (they use the F1 scratch)
+                    f3d[A.states[i]] = 1;  // 3-D field: LDS plane-tile kernels (they use the F1 scratch and one F2 array)
                     any_gather = true;
                 } else if (c->L->ctu_gather(c->g, sp, nullptr, nullptr, none, none, A.corner_transport, dt, c->touches,
                                             nullptr, nullptr, c->stream)) {
@@ -695,7 +695,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], (overlap ? 2 : 0) | tile_flag,
                             c->stream);
         else if (f3d[list[q]])
-            c->L->ctu_field3d(c->g, s.sp, s.new_data, s.alt, F1, ctu_flag[q], dt, c->touches, c->stream);
+            c->L->ctu_field3d(c->g, s.sp, s.new_data, s.alt, F1, c->gF2[0], ctu_flag[q], dt, c->touches, c->stream);
         else
             c->L->ctu_gather(c->g, s.sp, s.new_data, s.alt, F1, F2, ctu_flag[q], dt, c->touches, c->d_err, slots[q], c->stream);
     }

@@ -1,25 +1,27 @@
-// mfp_field3d.hip — z-marching corner-transport-upwind update of the field state (3-D), two passes.
+// mfp_field3d.hip — corner-transport-upwind update of the field state (3-D) from LDS plane tiles.
 //
 // HydroCTU::calc_spatial_derivative (MFP_CTU_hydro.cpp:142-531) + `new += dU` (MFP_advance.cpp:220-230)
 // for the Maxwell state on a 3-D block.  The one-launch pipeline of mfp_march3d.hip does not fit the
-// field: ten components with a 7-point stencil need a 70-value window per column along the marching
-// direction and ~90 carried values per column.  What makes the hydro pipeline deep are the transverse
-// corrections that wait for F_z of the next plane; with the sweep-1 fluxes in memory nothing waits:
+// field (ten components with a 7-point stencil: a 70-value window per column along the marching
+// direction), and a stencil gathered from memory along the marching direction misses L2 (measured:
+// 14 + 23 GB fetched per step at 256^3 against 1.3 + 4.6 GB needed; the resident workgroups' windows
+// are 9 MB per XCD against 4 MB of L2).  With the sweep-1 fluxes in memory nothing has to be carried
+// from plane to plane, so every direction can take its stencil from an LDS tile that contains it:
 //
-//   pass 1  k_f3d_flux1:   reconstruction + half-step trace of every cell, once, direction by direction;
-//                          Riemann sweep 1 -> F1[x], F1[y], F1[z] (8 components each) to memory
-//   pass 2  k_f3d_update:  the same reconstruction again (linear, cheap), transverse corrections from F1
-//                          (EulerianState::correct_face_prim MFP_eulerian.cpp:1047-1188: (d1+1)%3 then
-//                          (d1+2)%3), domain-face BCs, Riemann sweep 2, divergence, Uout = Uin + dU
+//   pass 1  k_f3d_xy<1>:  (x, y) tiles marching along z: reconstruction + half-step trace in x and y,
+//                         Riemann sweep 1 -> F1[x], F1[y] (8 components each)
+//           k_f3d_z<1>:   (x, z) tiles marching along y: the same in z -> F1[z]
+//   pass 2  k_f3d_xy<2>:  x and y again (linear, cheap), transverse corrections from F1
+//                         (EulerianState::correct_face_prim MFP_eulerian.cpp:1047-1188: (d1+1)%3 then
+//                         (d1+2)%3), domain-face BCs, Riemann sweep 2, dU_xy = 0 + dt/dx dF_x + dt/dy dF_y
+//           k_f3d_z<2>:   z faces likewise, Uout = Uin + (dU_xy + dt/dz dF_z)   (calc_divergence order,
+//                         MFP_eulerian.cpp:1614-1662)
 //
-// Both are 16 x 16 workgroups that own a 14 x 14 column of cells and march along z: the x and y
-// stencils come from an LDS tile of the current plane (grown by the stencil half width), the
-// x-neighbour's face state through DPP row shifts, the y-neighbour's through LDS, the z-neighbour's is
-// carried by the thread; the z stencil is read from memory (each plane is read as centre once and six
-// times as a neighbour: L2 / Infinity Cache hits).  HBM traffic: U + F1 written once and read once
-// (624 B per cell against 160 B algorithmic) instead of the gather kernels' two flux sets and, per
-// face, two reconstructions whose 8-point stencils are gathered through L1/L2.  Same device functions
-// and operation order per value: STRICT results are bit-identical to the oracle and the gather kernels.
+// (x, y) workgroups are 16 x 16 threads owning 14 x 14 cells (the x-neighbour's face state comes
+// through DPP row shifts, the y-neighbour's through LDS); (x, z) workgroups are 16 cells wide in x
+// (no x neighbour is needed) and own 14 cells in z.  HBM traffic: U read four times (with the tile
+// halos), F1 and dU_xy written once and read once or twice.  Same device functions and operation order
+// per value: STRICT results are bit-identical to the oracle and the gather kernels.
 #include "mfp_march.h"
 
 namespace CMFP_NS {
@@ -92,29 +94,40 @@ CMFP_DEV void f3_recon_lds(const double (*Pm)[NP], int pc, int stride, double sp
         f3_faces<RECON>(st, n, speed, h, lo[n], hi[n]);
     }
 }
-template <int RECON, int NP>
-CMFP_DEV void f3_recon_z(const Geo& g, const double* __restrict__ U, const double (*Pm)[NP], int pc, long c, int kmin, int kmax,
-                         int m, double speed, double h, double* lo, double* hi) {
-    constexpr int SL = ReconTraits<RECON>::SL, H = SL / 2;
+
+// the (x, z) tile of row j: rows pz = 0 .. BZ + 2H - 1 are the planes kbase - H + pz (clamped), 16 cells in x
+template <int H, int NPZ>
+CMFP_DEV void f3z_fill(const Geo& g, const double* __restrict__ U, double (*dst)[NPZ], int i0, int j, int k0, int tid) {
+    const int xhi = g.n[0] + g.ng[0] - 1, zlo = -g.ng[2], zhi = g.n[2] + g.ng[2] - 1;
+    for (int t = tid; t < NPZ; t += 256) {
+        const int pz = t >> 4, px = t & 15;
+        int ci = i0 + px, ck = k0 + pz;
+        ci = ci > xhi ? xhi : ci;  // cells outside the array feed only values nobody uses
+        ck = ck < zlo ? zlo : (ck > zhi ? zhi : ck);
+        const long c = g.at(ci, j, ck);
 #pragma unroll
-    for (int n = 0; n < 10; ++n) {
-        double st[SL];
-#pragma unroll
-        for (int s = 0; s < SL; ++s) {
-            int k = m + s - H;
-            k = k < kmin ? kmin : (k > kmax ? kmax : k);  // planes outside the array feed only values nobody uses
-            st[s] = (s == H) ? Pm[n][pc] : U[c + (long)(k - m) * g.sk + n * g.sc];
-        }
-        f3_faces<RECON>(st, n, speed, h, lo[n], hi[n]);
+        for (int n = 0; n < 10; ++n) dst[n][t] = U[c + n * g.sc];
     }
 }
 
-// ------------------------------------------------------------------------------------------ pass 1
-// F1[d] on cells with index_d in [0, n_d] and the other indices in [-1, n] (the flux boxes grown by one
-// transversally, MFP_CTU_hydro.cpp:254-268).  Threads cover the index range [-1, n] plus a ring.
-template <int RECON>
-__global__ __launch_bounds__(256, 2) void k_f3d_flux1(Geo g, FieldParams P, const double* __restrict__ U, Ptr3 F1, double dt,
-                                                       SelF3 sel) {
+CMFP_DEV void f3_apply_bc(const int* rule, bool outside_is_L, double* L, double* R) {
+#pragma unroll
+    for (int n = 0; n < 10; ++n)
+        if (rule[n]) {
+            if (outside_is_L)
+                L[n] = rule[n] == FILL_ODD ? -R[n] : R[n];
+            else
+                R[n] = rule[n] == FILL_ODD ? -L[n] : L[n];
+        }
+}
+
+// -------------------------------------------------------------------------------- x and y directions
+// PASS 1: F1[d] on cells with index_d in [0, n_d] and the other indices in [-1, n] (the flux boxes grown
+// by one transversally, MFP_CTU_hydro.cpp:254-268); threads cover [-1, n] plus a ring (sel.lo = -1).
+// PASS 2: corrected face states, sweep 2, dU_xy on the valid cells (sel.lo = 0).
+template <int RECON, int PASS, bool HAS_BC>
+__global__ __launch_bounds__(256, 2) void k_f3d_xy(Geo g, FieldParams P, const double* __restrict__ U, Ptr3 F1, double* __restrict__ DU,
+                                                    double dt, FaceBC3f bc, SelF3 sel) {
     constexpr int H = ReconTraits<RECON>::SL / 2, BX = 16, PX = BX + 2 * H, NP = PX * PX, C = 256;
     __shared__ double Pq[10][NP];
     __shared__ double bufR[10][C];
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void k_f3d_flux1(Geo g, FieldParams P, cons
     const int tiles = sel.gx * sel.gy;
     const int segi = wg / tiles, tile = wg - segi * tiles;
     const int tiy = tile / sel.gx, tix = tile - tiy * sel.gx;
-    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
+    const int n0 = g.n[0], n1 = g.n[1];
     const int i = sel.lo + tix * 14 - 1 + tx, j = sel.lo + tiy * 14 - 1 + ty;  // this thread's column
     const int ka = sel.lo + segi * sel.seg;
     const int kend = sel.lo + sel.np - 1;
@@ -134,29 +147,34 @@ __global__ __launch_bounds__(256, 2) void k_f3d_flux1(Geo g, FieldParams P, cons
     const int pc = (ty + H) * PX + (tx + H);
     const double speed = P.fastest;
     const double hx = uni(0.5 * dt / g.dx[0]), hy = uni(0.5 * dt / g.dx[1]), hz = uni(0.5 * dt / g.dx[2]);
+    const double dtdx = uni(dt / g.dx[0]), dtdy = uni(dt / g.dx[1]);
     const bool inner = tx >= 1 && tx <= 14 && ty >= 1 && ty <= 14;
     const bool i_ok = i >= -1 && i <= n0, j_ok = j >= -1 && j <= n1;
-    const int kmin = -g.ng[2], kmax = n2 + g.ng[2] - 1;
-    const int ic = i < -g.ng[0] ? -g.ng[0] : (i > n0 + g.ng[0] - 1 ? n0 + g.ng[0] - 1 : i);
-    const int jc = j < -g.ng[1] ? -g.ng[1] : (j > n1 + g.ng[1] - 1 ? n1 + g.ng[1] - 1 : j);
+    const int ic = i < -g.ng[0] ? -g.ng[0] : (i > n0 + g.ng[0] - 2 ? n0 + g.ng[0] - 2 : i);  // c + sx stays inside
+    const int jc = j < -g.ng[1] ? -g.ng[1] : (j > n1 + g.ng[1] - 2 ? n1 + g.ng[1] - 2 : j);
     const long col = g.at(ic, jc, 0);
+    const long sx = 1, sy = g.sj, sz = g.sk;
 
-    double zhi_p[10];
+    for (int m = ka; m <= kb; ++m) {
+        const long c = col + (long)m * sz;
+        // transverse flux differences of this cell, dF_d = F1[d](c) - F1[d](c + e_d): requested before the
+        // tile fill so that all of the iteration's memory latency is paid once
+        double dFx[8], dFy[8], dFz[8];
+        if (PASS == 2) {
 #pragma unroll
-    for (int n = 0; n < 10; ++n) zhi_p[n] = 0.0;
-    // the first plane of a segment that is not the first plane of the range only supplies zhi
-    const int m0 = ka > sel.lo ? ka - 1 : ka;
-    for (int m = m0; m <= kb; ++m) {
-        const bool emit = m >= ka;
+            for (int n = 0; n < 8; ++n) {
+                dFx[n] = F1.p[0][c + n * g.sc] - F1.p[0][c + sx + n * g.sc];
+                dFy[n] = F1.p[1][c + n * g.sc] - F1.p[1][c + sy + n * g.sc];
+                dFz[n] = F1.p[2][c + n * g.sc] - F1.p[2][c + sz + n * g.sc];
+            }
+        }
         __syncthreads();
         f3_fill<H, PX, NP>(g, U, Pq, i - tx - H, j - ty - H, m, tid);
         __syncthreads();
-        const long c = col + (long)m * g.sk;
-        double lo[10], hi[10], F[10];
-        if (emit) {
+        double lo[10], hi[10], F[10], L[10];
+        if (PASS == 1) {
             // ---- x
             f3_recon_lds<RECON, NP>(Pq, pc, 1, speed, hx, lo, hi);
-            double L[10];
 #pragma unroll
             for (int n = 0; n < 10; ++n) L[n] = f3_row_left(hi[n]);
             FieldF<RECON>::riemann(P, 0, L, lo, F);
@@ -168,10 +186,7 @@ __global__ __launch_bounds__(256, 2) void k_f3d_flux1(Geo g, FieldParams P, cons
             f3_recon_lds<RECON, NP>(Pq, pc, PX, speed, hy, lo, hi);
 #pragma unroll
             for (int n = 0; n < 10; ++n) bufR[n][tid] = hi[n];
-        }
-        __syncthreads();
-        if (emit) {
-            double L[10];
+            __syncthreads();
 #pragma unroll
             for (int n = 0; n < 10; ++n) L[n] = bufR[n][ty >= 1 ? tid - BX : tid];
             FieldF<RECON>::riemann(P, 1, L, lo, F);
@@ -179,129 +194,10 @@ __global__ __launch_bounds__(256, 2) void k_f3d_flux1(Geo g, FieldParams P, cons
 #pragma unroll
                 for (int n = 0; n < 8; ++n) F1.p[1][c + n * g.sc] = F[n];
             }
-        }
-        // ---- z
-        f3_recon_z<RECON, NP>(g, U, Pq, pc, c, kmin, kmax, m, speed, hz, lo, hi);
-        if (emit && m >= 0) {
-            FieldF<RECON>::riemann(P, 2, zhi_p, lo, F);
-            if (inner && i_ok && j_ok) {
+        } else {
+            double du[8];
 #pragma unroll
-                for (int n = 0; n < 8; ++n) F1.p[2][c + n * g.sc] = F[n];
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < 10; ++n) zhi_p[n] = hi[n];
-    }
-}
-
-// ------------------------------------------------------------------------------------------ pass 2
-template <int RECON, bool HAS_BC>
-__global__ __launch_bounds__(256, 2) void k_f3d_update(Geo g, FieldParams P, const double* __restrict__ Uin, double* __restrict__ Uout,
-                                                        Ptr3 F1, double dt, FaceBC3f bc, SelF3 sel) {
-    constexpr int H = ReconTraits<RECON>::SL / 2, BX = 16, PX = BX + 2 * H, NP = PX * PX, C = 256;
-    __shared__ double Pq[10][NP];
-    __shared__ double bufR[10][C];
-    __shared__ double Fb[8][C];
-    dt = launch_dt(g, dt);
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * BX + tx;
-    const int per = (sel.n + 7) >> 3;
-    const int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (wg >= sel.n) return;
-    const int tiles = sel.gx * sel.gy;
-    const int segi = wg / tiles, tile = wg - segi * tiles;
-    const int tiy = tile / sel.gx, tix = tile - tiy * sel.gx;
-    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
-    const int i = tix * 14 - 1 + tx, j = tiy * 14 - 1 + ty;  // this thread's column (the tile grown by one)
-    const int ka = segi * sel.seg;
-    const int kb = (ka + sel.seg - 1 < n2 - 1) ? ka + sel.seg - 1 : n2 - 1;
-    const int pc = (ty + H) * PX + (tx + H);
-    const double speed = P.fastest;
-    const double hx = uni(0.5 * dt / g.dx[0]), hy = uni(0.5 * dt / g.dx[1]), hz = uni(0.5 * dt / g.dx[2]);
-    const double dtdx = uni(dt / g.dx[0]), dtdy = uni(dt / g.dx[1]), dtdz = uni(dt / g.dx[2]);
-    const bool own = tx >= 1 && tx <= 14 && ty >= 1 && ty <= 14 && i < n0 && j < n1;
-    const int kmin = -g.ng[2], kmax = n2 + g.ng[2] - 1;
-    const int ic = i > n0 ? n0 : i, jc = j > n1 ? n1 : j;  // i, j >= -1; columns past the ring re-read it
-    const long col = g.at(ic, jc, 0);
-    const long sx = 1, sy = g.sj, sz = g.sk;
-
-    // carried from plane m - 1: corrected high z-face state, F'_z on its low face, dU after x and y
-    double zhiC_p[10], fz2_p[8], du_p[8];
-#pragma unroll
-    for (int n = 0; n < 10; ++n) zhiC_p[n] = 0.0;
-#pragma unroll
-    for (int n = 0; n < 8; ++n) fz2_p[n] = du_p[n] = 0.0;
-
-    for (int m = ka - 1; m <= kb + 1; ++m) {
-        __syncthreads();
-        f3_fill<H, PX, NP>(g, Uin, Pq, i - tx - H, j - ty - H, m, tid);
-        __syncthreads();
-        const long c = col + (long)m * sz;
-        // transverse flux differences of this cell, dF_d = F1[d](c) - F1[d](c + e_d): two of the three are
-        // live at a time (z-faces: x, y; x-faces: y, z; y-faces: z, x), the third is (re)loaded
-        double dFx[8], dFy[8], dFz[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            dFx[n] = F1.p[0][c + n * g.sc] - F1.p[0][c + sx + n * g.sc];
-            dFy[n] = F1.p[1][c + n * g.sc] - F1.p[1][c + sy + n * g.sc];
-        }
-        const bool full = m >= ka && m <= kb;  // plane whose x and y fluxes are needed (the others only supply z-face states)
-        double lo[10], hi[10], F[10];
-        // ---- z faces first (they complete plane m - 1, whose carried values then die): dF_x then dF_y
-        f3_recon_z<RECON, NP>(g, Uin, Pq, pc, c, kmin, kmax, m, speed, hz, lo, hi);
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            hi[n] += hx * dFx[n];
-            lo[n] += hx * dFx[n];
-            hi[n] += hy * dFy[n];
-            lo[n] += hy * dFy[n];
-        }
-        if (m >= ka) {
-            double L[10], R[10], fz2[10];
-#pragma unroll
-            for (int n = 0; n < 10; ++n) {
-                L[n] = zhiC_p[n];
-                R[n] = lo[n];
-            }
-            if (HAS_BC && bc.touch[2][0] && m == 0) {
-#pragma unroll
-                for (int n = 0; n < 10; ++n)
-                    if (bc.rule[2][0][n]) L[n] = bc.rule[2][0][n] == FILL_ODD ? -R[n] : R[n];
-            }
-            if (HAS_BC && bc.touch[2][1] && m == n2) {
-#pragma unroll
-                for (int n = 0; n < 10; ++n)
-                    if (bc.rule[2][1][n]) R[n] = bc.rule[2][1][n] == FILL_ODD ? -L[n] : L[n];
-            }
-            FieldF<RECON>::riemann(P, 2, L, R, fz2);
-            // ---- plane m - 1 is complete: divergence (calc_divergence MFP_eulerian.cpp:1614-1662), new += dU
-            if (m > ka && own) {
-                const long cm = c - sz;
-#pragma unroll
-                for (int n = 0; n < 10; ++n) {
-                    double d = 0.0;
-                    if (n < 8) {
-                        d = du_p[n];  // 0 + dt/dx (F_x - F_x+) + dt/dy (F_y - F_y+), accumulated in that order
-                        d += dtdz * (fz2_p[n] - fz2[n]);
-                    } else {  // F[mu] = F[ep] = 0 (MFP_field_RH.cpp:33)
-                        d += dtdx * (0.0 - 0.0);
-                        d += dtdy * (0.0 - 0.0);
-                        d += dtdz * (0.0 - 0.0);
-                    }
-                    Uout[cm + n * g.sc] = Uin[cm + n * g.sc] + d;
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < 8; ++n) fz2_p[n] = fz2[n];
-        }
-#pragma unroll
-        for (int n = 0; n < 10; ++n) zhiC_p[n] = hi[n];
-
-        double du[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) du[n] = 0.0;
-        if (full) {
-#pragma unroll
-            for (int n = 0; n < 8; ++n) dFz[n] = F1.p[2][c + n * g.sc] - F1.p[2][c + sz + n * g.sc];
+            for (int n = 0; n < 8; ++n) du[n] = 0.0;
             // ---- x faces: corrected with dF_y then dF_z
             f3_recon_lds<RECON, NP>(Pq, pc, 1, speed, hx, lo, hi);
 #pragma unroll
@@ -311,76 +207,150 @@ __global__ __launch_bounds__(256, 2) void k_f3d_update(Geo g, FieldParams P, con
                 hi[n] += hz * dFz[n];
                 lo[n] += hz * dFz[n];
             }
-            double L[10], R[10];
 #pragma unroll
-            for (int n = 0; n < 10; ++n) {
-                L[n] = f3_row_left(hi[n]);
-                R[n] = lo[n];
-            }
-            if (HAS_BC && bc.touch[0][0] && i == 0) {
-#pragma unroll
-                for (int n = 0; n < 10; ++n)
-                    if (bc.rule[0][0][n]) L[n] = bc.rule[0][0][n] == FILL_ODD ? -R[n] : R[n];
-            }
-            if (HAS_BC && bc.touch[0][1] && i == n0) {
-#pragma unroll
-                for (int n = 0; n < 10; ++n)
-                    if (bc.rule[0][1][n]) R[n] = bc.rule[0][1][n] == FILL_ODD ? -L[n] : L[n];
-            }
-            FieldF<RECON>::riemann(P, 0, L, R, F);
+            for (int n = 0; n < 10; ++n) L[n] = f3_row_left(hi[n]);
+            if (HAS_BC && bc.touch[0][0] && i == 0) f3_apply_bc(bc.rule[0][0], true, L, lo);
+            if (HAS_BC && bc.touch[0][1] && i == n0) f3_apply_bc(bc.rule[0][1], false, L, lo);
+            FieldF<RECON>::riemann(P, 0, L, lo, F);
 #pragma unroll
             for (int n = 0; n < 8; ++n) du[n] += dtdx * (F[n] - f3_row_right(F[n]));
-            // ---- y faces: corrected with dF_z then dF_x (reloaded)
+            // ---- y faces: corrected with dF_z then dF_x
             f3_recon_lds<RECON, NP>(Pq, pc, PX, speed, hy, lo, hi);
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
-                const double dfx = F1.p[0][c + n * g.sc] - F1.p[0][c + sx + n * g.sc];
                 hi[n] += hz * dFz[n];
                 lo[n] += hz * dFz[n];
-                hi[n] += hx * dfx;
-                lo[n] += hx * dfx;
+                hi[n] += hx * dFx[n];
+                lo[n] += hx * dFx[n];
             }
 #pragma unroll
             for (int n = 0; n < 10; ++n) bufR[n][tid] = hi[n];
-        }
-        __syncthreads();
-        if (full) {
-            double L[10], R[10];
+            __syncthreads();
 #pragma unroll
-            for (int n = 0; n < 10; ++n) {
-                L[n] = bufR[n][ty >= 1 ? tid - BX : tid];
-                R[n] = lo[n];
+            for (int n = 0; n < 10; ++n) L[n] = bufR[n][ty >= 1 ? tid - BX : tid];
+            if (HAS_BC && bc.touch[1][0] && j == 0) f3_apply_bc(bc.rule[1][0], true, L, lo);
+            if (HAS_BC && bc.touch[1][1] && j == n1) f3_apply_bc(bc.rule[1][1], false, L, lo);
+            FieldF<RECON>::riemann(P, 1, L, lo, F);
+            __syncthreads();  // every thread has read its neighbour's face state: the buffer takes the fluxes
+#pragma unroll
+            for (int n = 0; n < 8; ++n) bufR[n][tid] = F[n];
+            __syncthreads();
+            if (inner && i < n0 && j < n1) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    du[n] += dtdy * (F[n] - bufR[n][tid + BX]);
+                    DU[c + n * g.sc] = du[n];
+                }
             }
-            if (HAS_BC && bc.touch[1][0] && j == 0) {
-#pragma unroll
-                for (int n = 0; n < 10; ++n)
-                    if (bc.rule[1][0][n]) L[n] = bc.rule[1][0][n] == FILL_ODD ? -R[n] : R[n];
-            }
-            if (HAS_BC && bc.touch[1][1] && j == n1) {
-#pragma unroll
-                for (int n = 0; n < 10; ++n)
-                    if (bc.rule[1][1][n]) R[n] = bc.rule[1][1][n] == FILL_ODD ? -L[n] : L[n];
-            }
-            FieldF<RECON>::riemann(P, 1, L, R, F);
-#pragma unroll
-            for (int n = 0; n < 8; ++n) Fb[n][tid] = F[n];
         }
-        __syncthreads();
-        if (full) {
-#pragma unroll
-            for (int n = 0; n < 8; ++n) du[n] += dtdy * (F[n] - Fb[n][ty <= 14 ? tid + BX : tid]);
-        }
-#pragma unroll
-        for (int n = 0; n < 8; ++n) du_p[n] = du[n];
     }
 }
 
-static SelF3 make_sel(const Geo& g, int lo, int ext) {
+// -------------------------------------------------------------------------------------- z direction
+// Thread (tx, tz) of tile (tix, tiz): cell i = lo + 16 tix + tx, k = 14 tiz - 1 + tz; the workgroup marches
+// along y.  Faces k (between k - 1 and k) are computed by tz >= 1, cells are updated by tz in [1, 14].
+template <int RECON, int PASS, bool HAS_BC>
+__global__ __launch_bounds__(256, 3) void k_f3d_z(Geo g, FieldParams P, const double* __restrict__ Uin, double* __restrict__ Uout,
+                                                   Ptr3 F1, const double* __restrict__ DU, double dt, FaceBC3f bc, SelF3 sel) {
+    constexpr int H = ReconTraits<RECON>::SL / 2, BX = 16, NPZ = (16 + 2 * H) * BX, C = 256;
+    __shared__ double Pz[10][NPZ];
+    __shared__ double bufR[10][C];
+    dt = launch_dt(g, dt);
+    const int tx = threadIdx.x, tz = threadIdx.y, tid = tz * BX + tx;
+    const int per = (sel.n + 7) >> 3;
+    const int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (wg >= sel.n) return;
+    const int tiles = sel.gx * sel.gy;  // gy: tiles along z
+    const int segi = wg / tiles, tile = wg - segi * tiles;
+    const int tiz = tile / sel.gx, tix = tile - tiz * sel.gx;
+    const int n0 = g.n[0], n2 = g.n[2];
+    const int i = sel.lo + tix * 16 + tx, k = tiz * 14 - 1 + tz;
+    const int ja = sel.lo + segi * sel.seg;
+    const int jend = sel.lo + sel.np - 1;
+    const int jb = (ja + sel.seg - 1 < jend) ? ja + sel.seg - 1 : jend;
+    const int pc = (tz + H) * BX + tx;
+    const double speed = P.fastest;
+    const double hx = uni(0.5 * dt / g.dx[0]), hy = uni(0.5 * dt / g.dx[1]), hz = uni(0.5 * dt / g.dx[2]);
+    const double dtdx = uni(dt / g.dx[0]), dtdy = uni(dt / g.dx[1]), dtdz = uni(dt / g.dx[2]);
+    const int ic = i > n0 + g.ng[0] - 2 ? n0 + g.ng[0] - 2 : i;  // i >= -1; c + sx stays inside
+    const int kc = k > n2 + g.ng[2] - 1 ? n2 + g.ng[2] - 1 : k;  // k >= -1
+    const long base = g.at(ic, 0, kc);
+    const long sx = 1, sy = g.sj;
+    const bool face = tz >= 1 && k <= n2;
+
+    for (int j = ja; j <= jb; ++j) {
+        const long c = base + (long)j * sy;
+        // requested before the tile fill so that all of the iteration's memory latency is paid once
+        double dFx[8], dFy[8], du[8];
+        if (PASS == 2) {
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                dFx[n] = F1.p[0][c + n * g.sc] - F1.p[0][c + sx + n * g.sc];
+                dFy[n] = F1.p[1][c + n * g.sc] - F1.p[1][c + sy + n * g.sc];
+                du[n] = DU[c + n * g.sc];
+            }
+        }
+        __syncthreads();
+        f3z_fill<H, NPZ>(g, Uin, Pz, i - tx, j, k - tz - H, tid);
+        __syncthreads();
+        double lo[10], hi[10], F[10], L[10];
+        f3_recon_lds<RECON, NPZ>(Pz, pc, BX, speed, hz, lo, hi);
+        if (PASS == 2) {
+            // z faces: corrected with dF_x then dF_y
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                hi[n] += hx * dFx[n];
+                lo[n] += hx * dFx[n];
+                hi[n] += hy * dFy[n];
+                lo[n] += hy * dFy[n];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 10; ++n) bufR[n][tid] = hi[n];
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 10; ++n) L[n] = bufR[n][tz >= 1 ? tid - BX : tid];
+        if (PASS == 2) {
+            if (HAS_BC && bc.touch[2][0] && k == 0) f3_apply_bc(bc.rule[2][0], true, L, lo);
+            if (HAS_BC && bc.touch[2][1] && k == n2) f3_apply_bc(bc.rule[2][1], false, L, lo);
+        }
+        FieldF<RECON>::riemann(P, 2, L, lo, F);
+        if (PASS == 1) {
+            if (face && tz <= 14 && i <= n0) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) F1.p[2][c + n * g.sc] = F[n];
+            }
+        } else {
+            __syncthreads();  // every thread has read its neighbour's face state: the buffer takes the fluxes
+#pragma unroll
+            for (int n = 0; n < 8; ++n) bufR[n][tid] = F[n];
+            __syncthreads();
+            if (tz >= 1 && tz <= 14 && k < n2 && i < n0) {
+#pragma unroll
+                for (int n = 0; n < 10; ++n) {
+                    double d = 0.0;
+                    if (n < 8) {
+                        d = du[n];  // 0 + dt/dx (F_x - F_x+) + dt/dy (F_y - F_y+), accumulated in that order
+                        d += dtdz * (F[n] - bufR[n][tid + BX]);
+                    } else {  // F[mu] = F[ep] = 0 (MFP_field_RH.cpp:33)
+                        d += dtdx * (0.0 - 0.0);
+                        d += dtdy * (0.0 - 0.0);
+                        d += dtdz * (0.0 - 0.0);
+                    }
+                    Uout[c + n * g.sc] = Pz[n][pc] + d;  // the tile holds Uin
+                }
+            }
+        }
+    }
+}
+
+// tiles of `tw` cells over `nx` cells in the first tile dimension and 14 over `ny` in the second, marching over `np`
+static SelF3 make_sel(int nx, int tw, int ny, int np, int lo) {
     SelF3 s;
     s.lo = lo;
-    s.gx = (g.n[0] + ext + 13) / 14;
-    s.gy = (g.n[1] + ext + 13) / 14;
-    s.np = g.n[2] + ext;
+    s.gx = (nx + tw - 1) / tw;
+    s.gy = (ny + 13) / 14;
+    s.np = np;
     const int tiles = s.gx * s.gy;
     int nseg = (2 * wave_slots() + tiles - 1) / tiles;  // as in mfp_march3d.hip: eight rounds of resident workgroups
     if (nseg < 1) nseg = 1;
@@ -393,7 +363,7 @@ static SelF3 make_sel(const Geo& g, int lo, int ext) {
 }
 
 template <int RECON>
-static int launch_f3d(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, double dt,
+static int launch_f3d(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, double* DU, double dt,
                       const int touches[3][2], hipStream_t st) {
     constexpr int H = ReconTraits<RECON>::SL / 2;
     if (g.ng[0] < H + 1 || g.ng[1] < H + 1 || g.ng[2] < H + 1) return 0;
@@ -410,23 +380,34 @@ static int launch_f3d(const Geo& g, const StatePhys& sp, const double* Uin, doub
             }
         }
     const dim3 block(16, 16);
-    const SelF3 s1 = make_sel(g, -1, 2);  // cells [-1, n] in every dimension
-    hipLaunchKernelGGL((k_f3d_flux1<RECON>), dim3(((s1.n + 7) / 8) * 8), block, 0, st, g, sp.fp, Uin, F1, dt, s1);
-    const SelF3 s2 = make_sel(g, 0, 0);
-    if (has_bc)
-        hipLaunchKernelGGL((k_f3d_update<RECON, true>), dim3(((s2.n + 7) / 8) * 8), block, 0, st, g, sp.fp, Uin, Uout, F1, dt, bc, s2);
-    else
-        hipLaunchKernelGGL((k_f3d_update<RECON, false>), dim3(((s2.n + 7) / 8) * 8), block, 0, st, g, sp.fp, Uin, Uout, F1, dt, bc, s2);
+    auto grid = [](const SelF3& s) { return dim3(((s.n + 7) / 8) * 8); };
+    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
+    // pass 1: cells [-1, n] in every dimension (z faces: 0 .. n2)
+    const SelF3 a = make_sel(n0 + 2, 14, n1 + 2, n2 + 2, -1);
+    hipLaunchKernelGGL((k_f3d_xy<RECON, 1, false>), grid(a), block, 0, st, g, sp.fp, Uin, F1, DU, dt, bc, a);
+    const SelF3 b = make_sel(n0 + 2, 16, n2 + 1, n1 + 2, -1);
+    hipLaunchKernelGGL((k_f3d_z<RECON, 1, false>), grid(b), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, b);
+    // pass 2: the valid cells
+    const SelF3 c = make_sel(n0, 14, n1, n2, 0);
+    const SelF3 d = make_sel(n0, 16, n2, n1, 0);
+    if (has_bc) {
+        hipLaunchKernelGGL((k_f3d_xy<RECON, 2, true>), grid(c), block, 0, st, g, sp.fp, Uin, F1, DU, dt, bc, c);
+        hipLaunchKernelGGL((k_f3d_z<RECON, 2, true>), grid(d), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, d);
+    } else {
+        hipLaunchKernelGGL((k_f3d_xy<RECON, 2, false>), grid(c), block, 0, st, g, sp.fp, Uin, F1, DU, dt, bc, c);
+        hipLaunchKernelGGL((k_f3d_z<RECON, 2, false>), grid(d), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, d);
+    }
     return 1;
 }
 
-// Two-pass z-marching update of a 3-D field state; F1: sweep-1 flux scratch (8 planes per direction).
-// Returns 0 where the option set is outside these kernels (the caller then uses the gather kernels).
-int ctu_field3d(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, int do_ctu, double dt,
-                const int touches[3][2], hipStream_t st) {
+// Update of a 3-D field state from LDS plane tiles; F1: sweep-1 flux scratch, DU: dU_xy scratch (8 planes
+// each).  Returns 0 where the option set is outside these kernels (the caller then uses the gather kernels).
+int ctu_field3d(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, double* DU, int do_ctu,
+                double dt, const int touches[3][2], hipStream_t st) {
     if (g.dim != 3 || sp.kind != 1 || !do_ctu || sp.flux != 10) return 0;
-    if (sp.recon == 5) return launch_f3d<5>(g, sp, Uin, Uout, F1, dt, touches, st);
-    if (sp.recon == 2) return launch_f3d<2>(g, sp, Uin, Uout, F1, dt, touches, st);
+    if (sp.recon == 5) return launch_f3d<5>(g, sp, Uin, Uout, F1, DU, dt, touches, st);
+    if (sp.recon == 1) return launch_f3d<1>(g, sp, Uin, Uout, F1, DU, dt, touches, st);
+    if (sp.recon == 2) return launch_f3d<2>(g, sp, Uin, Uout, F1, DU, dt, touches, st);
     return 0;
 }
 

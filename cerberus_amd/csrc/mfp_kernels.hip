@@ -1357,7 +1357,7 @@ int ctu_fused(const Geo&, const StatePhys&, const double* Uin, double* Uout, int
 CMFP_GATHER_DECL(1) CMFP_GATHER_DECL(2) CMFP_GATHER_DECL(3)
 #undef CMFP_GATHER_DECL
 // defined in mfp_field3d.hip
-int ctu_field3d(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, int do_ctu, double dt,
+int ctu_field3d(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, double* DU, int do_ctu, double dt,
                 const int touches[3][2], hipStream_t);
 static int l_ctu_gather(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
                         int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {

@@ -164,7 +164,7 @@ struct Launchers {
     int (*ctu_gather)(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
                       int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
     // two-pass z-marching update of a 3-D field state (mfp_field3d.hip); F1: sweep-1 flux scratch
-    int (*ctu_field3d)(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, int do_ctu, double dt,
+    int (*ctu_field3d)(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, double* DU, int do_ctu, double dt,
                        const int touches[3][2], hipStream_t);
     // batched leaves
     int (*leaf_reconstruct)(int recon, long n, const double* st, double* slope, double* lo, double* hi, hipStream_t);

@@ -505,3 +505,32 @@ def test_march3d_hydro(oracle, recon, flux, walls):
         assert dts == dts_ref, (fused, dts, dts_ref)
         assert np.array_equal(m.download(0), ref.get_state(0)), (recon, flux, walls, fused)
         m.close()
+
+
+# ---- 3-D field update from LDS plane tiles (mfp_field3d.hip) ---------------------------------------
+@pytest.mark.parametrize("recon,walls", [("O6", False), ("O6", True), ("vanLeer", True), ("minmod", True)])
+def test_field3d_tiles(oracle, recon, walls):
+    """two-fluid + Maxwell 3-D block on the plane-tile field kernels: partial tiles in every direction,
+    several marching segments, conducting walls / outflow on all six faces of the field: bit-identical
+    to the oracle and to the gather kernels."""
+    cfg = problems.richtmyer_meshkov_3d(20, 17, 40)
+    cfg["states"]["field"]["reconstruction"] = recon
+    if walls:
+        cfg["is_periodic"] = [0, 0, 0]
+        hw = {"lo": {"fill_hydro_bc": "slipwall"}, "hi": {"fill_hydro_bc": "slipwall"}}
+        fw = {k: {"fill_D_bc": "asymmetry", "fill_B_bc": "asymmetry", "fill_phi_bc": "symmetry", "fill_psi_bc": "symmetry",
+                  "fill_mu_bc": "symmetry", "fill_ep_bc": "symmetry"} for k in ("lo", "hi")}
+        fo = {"lo": {}, "hi": fw["hi"]}
+        for name in ("ion", "electron"):
+            cfg["states"][name]["bc"] = {"x": hw, "y": hw, "z": hw}
+        cfg["states"]["field"]["bc"] = {"x": fw, "y": fo, "z": fw}
+    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    ref = oracle.OracleSim(P)
+    dts_ref = ref.run(3)
+    for fused in (True, 2):
+        m = _gpu(P, fused=fused)
+        dts = m.run(3)
+        assert dts == dts_ref, (fused, dts, dts_ref)
+        for s in range(3):
+            assert np.array_equal(m.download(s), ref.get_state(s)), (recon, walls, fused, P.state_names[s])
+        m.close()
