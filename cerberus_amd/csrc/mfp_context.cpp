@@ -13,6 +13,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -79,6 +80,7 @@ struct cmfp_context {
     cmfp_exchange_fn exchange = nullptr;
     void* exchange_user = nullptr;
     int exchange_batched = 0;
+    int src_epilogue = 1;      // Strang stage C inside the field's CTU kernel where that applies (CMFP_SRC_EPILOGUE=0: never)
     int overlap = 1;           // 1: interior flux tiles overlap the halo exchange where the block is split; 2: always split the launches
     hipStream_t stream2 = nullptr;  // interior tiles run here while ghost cells are in flight on `stream`
     hipEvent_t ev_src = nullptr, ev_int = nullptr;  // one callback per dimension for all states (state = CMFP_ALL_STATES)
@@ -638,6 +640,31 @@ int advance_strang_fused(cmfp_context* c, double dt) {
                 list.push_back(A.states[i]);
                 ctu_flag.push_back(A.corner_transport);
             }
+    // Strang stage C as the epilogue of the field's CTU kernel (the last launch of the step): explicit
+    // plasma5 / Lorentz over species that are all CTU states, 2-D tiled field kernel
+    int epi_q = -1;
+    SourceEpi epi;
+    std::memset(&epi, 0, sizeof(epi));
+    if (src >= 0 && coll < 0 && c->src_epilogue && c->fused == 1) {
+        const cmfp_action_desc& SA = c->actions[src];
+        const int fs = SA.states[SA.n_states - 1];
+        bool ok = SA.n_states - 1 <= 2 && tiled[fs] && c->states[fs].sp.kind == CMFP_STATE_FIELD &&
+                  !(SA.kind == CMFP_ACTION_PLASMA5 && SA.solver == CMFP_SOLVER_IMPLICIT);
+        for (size_t q = 0; q < list.size(); ++q)
+            if (list[q] == fs) epi_q = (int)q;
+        ok = ok && epi_q >= 0;
+        for (int n = 0; n < SA.n_states - 1 && ok; ++n) {
+            bool in_list = false;
+            for (int v : list) in_list = in_list || v == SA.states[n];
+            ok = in_list && c->states[SA.states[n]].sp.kind == CMFP_STATE_HYDRO;
+        }
+        if (ok) {
+            epi.ns = SA.n_states - 1;
+            epi.a = source_args(c, SA, true);
+            ok = c->L->ctu_field_src(c->g, c->states[fs].sp, nullptr, nullptr, ctu_flag[epi_q], dt, c->touches, epi, 0, c->stream) != 0;
+        }
+        if (!ok) epi_q = -1;
+    }
     // Halo/compute overlap: where the block is split between ranks, the flux update of the tiles
     // whose stencils stay inside valid cells runs on a second stream while the ghost layers are
     // packed, exchanged and unpacked on the main one; the frame of boundary tiles follows the fill.
@@ -670,15 +697,34 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             HIPCHK(c, hipMemsetAsync(slots[q], 0, 256 * sizeof(unsigned long long), c->stream));
         }
     }
+    std::vector<size_t> order;  // launch order: the field with the source epilogue goes last
+    for (size_t q = 0; q < list.size(); ++q)
+        if ((int)q != epi_q) order.push_back(q);
+    if (epi_q >= 0) {
+        order.push_back((size_t)epi_q);
+        const cmfp_action_desc& SA = c->actions[src];
+        const int ns = (int)c->states.size();
+        for (int n = 0; n < epi.ns; ++n) {
+            epi.a.sp_U[n] = c->states[SA.states[n]].alt;  // where the species' CTU kernels write
+            epi.red_speed[n] = reinterpret_cast<unsigned long long*>(c->d_part + (size_t)SA.states[n] * CMFP_RED_BLOCKS);
+            HIPCHK(c, hipMemsetAsync(epi.red_speed[n], 0, 256 * sizeof(unsigned long long), c->stream));
+        }
+        epi.red_dt = reinterpret_cast<unsigned long long*>(c->d_part + (size_t)(ns + src) * CMFP_RED_BLOCKS);
+        HIPCHK(c, hipMemsetAsync(epi.red_dt, 0xff, 256 * sizeof(unsigned long long), c->stream));  // all-ones: empty (a NaN to fmin)
+        c->L->source_coef(epi.a, 0.5 * dt, epi.kf);
+    }
     const Ptr3 F1{{c->gF1[0], c->gF1[1], c->gF1[2]}}, F2{{c->gF2[0], c->gF2[1], c->gF2[2]}};
     auto slot_of = [&](const StateRT& s) { return s.sp.kind == CMFP_STATE_HYDRO ? CMFP_PROF_CTU_HYDRO : CMFP_PROF_CTU_FIELD; };
     if (overlap) {
         HIPCHK(c, hipEventRecord(c->ev_src, c->stream));  // source stage A (and the slot resets) done
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_src, 0));
-        for (size_t q = 0; q < list.size(); ++q) {
+        for (size_t q : order) {
             StateRT& s = c->states[list[q]];
             ProfScope prof(c, slot_of(s), c->stream2, true);
-            c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], 1 | tile_flag, c->stream2);
+            if ((int)q == epi_q)
+                c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, 1, c->stream2);
+            else
+                c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], 1 | tile_flag, c->stream2);
         }
         HIPCHK(c, hipEventRecord(c->ev_int, c->stream2));
     }
@@ -688,10 +734,12 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         int r;
         if ((r = fill_patch_many(c, list))) return r;
     }
-    for (size_t q = 0; q < list.size(); ++q) {
+    for (size_t q : order) {
         StateRT& s = c->states[list[q]];
         ProfScope prof(c, slot_of(s), c->stream, !overlap);
-        if (tiled[list[q]])
+        if ((int)q == epi_q)
+            c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, overlap ? 2 : 0, c->stream);
+        else if (tiled[list[q]])
             c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], (overlap ? 2 : 0) | tile_flag,
                             c->stream);
         else if (f3d[list[q]])
@@ -708,7 +756,19 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         }
         std::swap(s.new_data, s.alt);
     }
-    if (src >= 0) {
+    if (epi_q >= 0) {
+        // stage C ran inside the field kernel: fold its reduction slots
+        const cmfp_action_desc& A = c->actions[src];
+        const int ns = (int)c->states.size();
+        for (int n = 0; n < epi.ns; ++n) {
+            c->L->reduce_final(reinterpret_cast<const double*>(epi.red_speed[n]), 256, 1, c->d_red + A.states[n], c->stream);
+            c->red_valid[A.states[n]] = 1;
+        }
+        if (epi.a.limits_dt) {
+            c->L->reduce_final(reinterpret_cast<const double*>(epi.red_dt), 256, 0, c->d_red + ns + src, c->stream);
+            c->red_valid[c->states.size() + src] = 1;
+        }
+    } else if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
         if (coll >= 0) a.coll = coll_args(c, c->actions[coll]);
         ProfScope prof(c, CMFP_PROF_SOURCE);
@@ -759,6 +819,7 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     c->params = *params;
     c->device = device;
     c->stream = (hipStream_t)stream;
+    if (const char* e = std::getenv("CMFP_SRC_EPILOGUE")) c->src_epilogue = std::atoi(e) != 0;
     c->L = params->fp_mode == CMFP_FP_FAST ? fast::launchers() : strict::launchers();
     c->nsteps = params->time_integrator == CMFP_TI_EULER ? 1 : 2;  // MFP_config.cpp:73-81
     HIPCHK(c, hipSetDevice(device));

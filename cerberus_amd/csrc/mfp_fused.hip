@@ -17,6 +17,7 @@
 // same sequence of operations as the staged kernels (same device functions), so
 // results are identical to them bit for bit.
 #include "mfp_device.h"
+#include "mfp_source.h"
 
 namespace CMFP_NS {
 using namespace cmfp;
@@ -82,10 +83,17 @@ __device__ __forceinline__ void tile_of(const TileSel& s, int t, int& tix, int& 
     }
 }
 
-template <class Phys, int BX, int BY, bool HAS_BC, bool REDUCE>
+// kernel argument of the source epilogue (SRC species; nothing without one)
+struct NoEpi {};
+template <int SRC> struct EpiArg { typedef SourceEpi type; };
+template <> struct EpiArg<0> { typedef NoEpi type; };
+
+// SRC > 0 (field states): the explicit Strang source stage C (k_source_rk2's arithmetic) of SRC species is
+// applied to the cells this kernel updates, with the CFL reductions of what it writes.
+template <class Phys, int BX, int BY, bool HAS_BC, bool REDUCE, int SRC = 0>
 __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
                                                    double* __restrict__ Uout, int do_ctu, double dt, FaceBC bc, int* err,
-                                                   TileSel sel, unsigned long long* red) {
+                                                   TileSel sel, unsigned long long* red, typename EpiArg<SRC>::type epi) {
     constexpr int NQ = Phys::NQ, NC = Phys::NC, NF = Phys::NF, RECON = Phys::RECON;
     constexpr int SL = ReconTraits<RECON>::SL, H = SL / 2;
     constexpr int TX = BX - 2, TY = BY - 2;
@@ -328,6 +336,9 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
     STAMP(9);
 
     double red_speed = 2.2250738585072014e-308;  // std::numeric_limits<Real>::min(), MFP_eulerian.cpp:265
+    double src_speed[SRC > 0 ? SRC : 1], src_dt = DBL_MAX;
+#pragma unroll
+    for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s) src_speed[s] = DBL_MIN;
     // ---- phase 5: divergence (calc_divergence MFP_eulerian.cpp:1614-1662) and new += dU
     if (tx >= 1 && tx <= BX - 2 && ty >= 1 && ty <= BY - 2 && i < n0 && j < n1) {
         const long c = g.at(i, j, 0);
@@ -344,7 +355,43 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
                 du += dtdy * (0.0 - 0.0);
             }
             Unew[n] = Uin[c + n * g.sc] + du;
-            Uout[c + n * g.sc] = Unew[n];
+            if constexpr (SRC == 0) Uout[c + n * g.sc] = Unew[n];
+        }
+        if constexpr (SRC > 0) {
+            // Strang stage C on this cell (MFP_advance.cpp:235-281): the species were updated by their own
+            // CTU kernels before this launch; in place on their new-time data
+            const SourceArgs& a = epi.a;
+            const double hdt = 0.5 * dt;
+            SourceCoef kf{epi.kf[0], epi.kf[1], epi.kf[2]};
+            if (g.dtp) kf = source_coef(a, hdt);
+            double s0[SRC][5], snew[SRC][4], fnew[5];
+#pragma unroll
+            for (int s = 0; s < SRC; ++s)
+#pragma unroll
+                for (int n = 0; n < 5; ++n) s0[s][n] = a.sp_U[s][c + n * g.sc];
+            source_rk2_explicit_cell<SRC>(a, kf, hdt, Unew, s0, fnew, snew);
+#pragma unroll
+            for (int s = 0; s < SRC; ++s) {
+                double Un[5];
+                Un[0] = s0[s][0];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    Un[n + 1] = snew[s][n];
+                    a.sp_U[s][c + (n + 1) * g.sc] = snew[s][n];
+                }
+                GasP G{1.0, 0.0, a.gamma[s]};
+                src_speed[s] = cell_max_speed(G, Un, g.dim, src_speed[s]);
+                if (a.limits_dt) src_dt = cell_plasma_dt(a.Larmor, a.Debye, Unew[F_BX], Unew[F_BY], Unew[F_BZ], Un[0], a.r[s], src_dt);
+            }
+            if (!a.lorentz_only) {
+                Unew[F_DX] = fnew[0];
+                Unew[F_DY] = fnew[1];
+                Unew[F_DZ] = fnew[2];
+                Unew[F_PHI] = fnew[3];
+                Unew[F_PSI] = fnew[4];
+            }
+#pragma unroll
+            for (int n = 0; n < NC; ++n) Uout[c + n * g.sc] = Unew[n];
         }
         if constexpr (Phys::IS_HYDRO && REDUCE) {
             {  // EulerianState::get_allowed_time_step MFP_eulerian.cpp:290-296 on the values just written
@@ -368,6 +415,33 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
                 for (int w2 = 1; w2 < C / 64; ++w2) red_speed = fmax(red_speed, shr[w2]);
                 atomicMax(&red[tile & 255], (unsigned long long)__double_as_longlong(red_speed));
             }
+        }
+    }
+    if constexpr (SRC > 0) {
+        // the reductions k_source_rk2<REDUCE> leaves: wave, workgroup (LDS), one integer atomic per word
+        double* const shr = bufR;  // free since the barrier that ended phase 4
+#pragma unroll
+        for (int s = 0; s < SRC; ++s)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) src_speed[s] = fmax(src_speed[s], __shfl_xor(src_speed[s], o, 64));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) src_dt = fmin(src_dt, __shfl_xor(src_dt, o, 64));
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int s = 0; s < SRC; ++s) shr[(tid >> 6) * 4 + s] = src_speed[s];
+            shr[(tid >> 6) * 4 + 3] = src_dt;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w2 = 1; w2 < C / 64; ++w2) {
+#pragma unroll
+                for (int s = 0; s < SRC; ++s) src_speed[s] = fmax(src_speed[s], shr[w2 * 4 + s]);
+                src_dt = fmin(src_dt, shr[w2 * 4 + 3]);
+            }
+#pragma unroll
+            for (int s = 0; s < SRC; ++s)
+                atomicMax(&epi.red_speed[s][tile & 255], (unsigned long long)__double_as_longlong(src_speed[s]));
+            if (epi.a.limits_dt) atomicMin(&epi.red_dt[tile & 255], (unsigned long long)__double_as_longlong(src_dt));
         }
     }
     STAMP(10);
@@ -408,7 +482,7 @@ static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhy
     const dim3 grid(((sel.n + 7) / 8) * 8), block(BX, BY);
     const FaceBC bc = make_bc(sp, touches);
 #define CMFP_LAUNCH(BC, RED) \
-    hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, BC, RED>), grid, block, 0, st, g, P, Uin, Uout, do_ctu, dt, bc, err, sel, red)
+    hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, BC, RED>), grid, block, 0, st, g, P, Uin, Uout, do_ctu, dt, bc, err, sel, red, NoEpi{})
     if constexpr (Phys::IS_HYDRO) {
         if (red) {
             if (has_bc) CMFP_LAUNCH(true, true); else CMFP_LAUNCH(false, true);
@@ -417,6 +491,34 @@ static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhy
     }
     if (has_bc) CMFP_LAUNCH(true, false); else CMFP_LAUNCH(false, false);
 #undef CMFP_LAUNCH
+    return 1;
+}
+
+// the field update with the source epilogue: same tile selection as launch2d
+template <class Phys, int BX, int BY, int NS>
+static int launch2d_src(const Geo& g, const typename Phys::Params& P, const StatePhys& sp, const double* Uin, double* Uout,
+                        int do_ctu, double dt, const int touches[3][2], const SourceEpi& epi, int part, hipStream_t st) {
+    if (!Uin) return 1;  // coverage probe
+    constexpr int TX = BX - 2, TY = BY - 2, H = ReconTraits<Phys::RECON>::SL / 2;
+    TileSel sel;
+    sel.part = part;
+    sel.gx = (g.n[0] + TX - 1) / TX;
+    sel.gy = (g.n[1] + TY - 1) / TY;
+    sel.ix0 = sel.iy0 = 1;
+    sel.ix1 = g.n[0] - 1 - H - TX >= 0 ? (g.n[0] - 1 - H - TX) / TX : -1;
+    sel.iy1 = g.n[1] - 1 - H - TY >= 0 ? (g.n[1] - 1 - H - TY) / TY : -1;
+    const int n_int = (sel.ix1 >= sel.ix0 && sel.iy1 >= sel.iy0) ? (sel.ix1 - sel.ix0 + 1) * (sel.iy1 - sel.iy0 + 1) : 0;
+    sel.n = part == 0 ? sel.gx * sel.gy : part == 1 ? n_int : sel.gx * sel.gy - n_int;
+    if (sel.n <= 0) return 1;
+    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
+    const dim3 grid(((sel.n + 7) / 8) * 8), block(BX, BY);
+    const FaceBC bc = make_bc(sp, touches);
+    if (has_bc)
+        hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, true, false, NS>), grid, block, 0, st, g, P, Uin, Uout, do_ctu, dt, bc, nullptr, sel,
+                           nullptr, epi);
+    else
+        hipLaunchKernelGGL((k_ctu2d<Phys, BX, BY, false, false, NS>), grid, block, 0, st, g, P, Uin, Uout, do_ctu, dt, bc, nullptr, sel,
+                           nullptr, epi);
     return 1;
 }
 
@@ -469,6 +571,19 @@ int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout
     }
 #undef HY
 #undef FI
+    return 0;
+}
+
+// The tiled 2-D field update followed, per cell, by the explicit Strang source stage C of epi.ns species
+// (plasma5 explicit / Lorentz).  Same part semantics as ctu_fused; 0 where the option set is not covered.
+int ctu_field_src(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
+                  const int touches[3][2], const SourceEpi& epi, int part, hipStream_t st) {
+    if (g.dim != 2 || sp.kind != 1 || epi.a.implicit || epi.a.coll.on) return 0;
+#define FS(R, NS) \
+    if (sp.recon == R && epi.ns == NS) \
+        return launch2d_src<FieldF<R>, CMFP_FBX, CMFP_FBY, NS>(g, sp.fp, sp, Uin, Uout, do_ctu, dt, touches, epi, part, st);
+    FS(5, 2) FS(5, 1) FS(1, 2) FS(2, 2) FS(6, 2)
+#undef FS
     return 0;
 }
 

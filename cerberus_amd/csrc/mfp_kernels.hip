@@ -7,6 +7,7 @@
 // with the state's ghost width on every array, so one thread per cell gives
 // fully coalesced 8-byte lane accesses on every component plane.
 #include "mfp_device.h"
+#include "mfp_source.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -369,54 +370,6 @@ __global__ void k_lincomb(Geo g, IBox box, int nc, double* dst, double a, const 
 }
 
 // -------------------------------------------------------------------- sources
-struct SourceCoef {
-    double f1, f2, f3;
-};
-__host__ __device__ static inline SourceCoef source_coef(const SourceArgs& a, double dt) {
-    // MFP_plasma5.cpp:123-129
-    const double c_h = a.c_h;
-    const double c_d = a.div_damp != 0.0 ? c_h / a.div_damp : 0.0;
-    SourceCoef k;
-    k.f1 = dt * a.Larmor / (a.Debye * a.Debye * a.lightspeed);
-    k.f2 = dt * c_h * c_h * k.f1 / a.lightspeed;
-    k.f3 = c_d != 0.0 ? dt * c_h * c_h / (c_d * c_d) : 0.0;
-    return k;
-}
-
-// One cell of Plasma5::explicit_solve (MFP_plasma5.cpp:161-236) /
-// Lorentz::calc_time_derivative (MFP_lorentz.cpp:129-189).  fU: field comps,
-// sU[n]: species comps {rho,mx,my,mz,E}.  Outputs are the increments.
-template <int MAXS>
-CMFP_DEV void plasma5_explicit_cell(const SourceArgs& a, const SourceCoef& kf, double dt, const double* fU,
-                                    const double (*sU)[5], double (*sdU)[4], double* fdU /*Dx,Dy,Dz,phi,psi*/) {
-    const double Larmor = a.Larmor, lightspeed = a.lightspeed;
-    const double ep = fU[F_EP];
-    const double Bx = fU[F_BX], By = fU[F_BY], Bz = fU[F_BZ];
-    const double Ex = fU[F_DX] / ep, Ey = fU[F_DY] / ep, Ez = fU[F_DZ] / ep;
-    double charge_density = 0.0, current_x = 0.0, current_y = 0.0, current_z = 0.0;
-#pragma unroll
-    for (int n = 0; n < MAXS; ++n) {
-        if (n < a.n_species) {
-            const double rho = sU[n][0], mx = sU[n][1], my = sU[n][2], mz = sU[n][3];
-            const double r = a.r[n];
-            charge_density += rho * r;
-            current_x += r * mx;
-            current_y += r * my;
-            current_z += r * mz;
-            const double u = mx / rho, v = my / rho, w = mz / rho;
-            sdU[n][0] = dt * (rho * r / Larmor) * (lightspeed * Ex + v * Bz - w * By);
-            sdU[n][1] = dt * (rho * r / Larmor) * (lightspeed * Ey + w * Bx - u * Bz);
-            sdU[n][2] = dt * (rho * r / Larmor) * (lightspeed * Ez + u * By - v * Bx);
-            sdU[n][3] = dt * (rho * r * lightspeed) / Larmor * (u * Ex + v * Ey + w * Ez);
-        }
-    }
-    fdU[0] = -kf.f1 * current_x;
-    fdU[1] = -kf.f1 * current_y;
-    fdU[2] = -kf.f1 * current_z;
-    fdU[3] = -fU[F_PHI] * kf.f3 + kf.f2 * charge_density;
-    fdU[4] = -fU[F_PSI] * kf.f3;
-}
-
 // One cell of Collisions::calc_time_derivative (MFP_collisions.cpp:158-246) with
 // CollisionsRambo::calc_update (MFP_collisions_rambo.cpp:68-126), single-species states
 // (alpha = 1).  out[s][c] is what the reference adds to dU: (U + dt * delta) - U.
@@ -678,26 +631,6 @@ __global__ void k_reduce_final(const double* __restrict__ part, int nb, int is_m
         for (int w = 1; w < TPB / 64; ++w) v = is_max ? fmax(v, sh[w]) : fmin(v, sh[w]);
         *out = (unsigned long long)__double_as_longlong(v);
     }
-}
-
-// per-cell contributions
-// EulerianState::get_allowed_time_step MFP_eulerian.cpp:290-296
-CMFP_DEV double cell_max_speed(const GasP& G, const double* U, int dim, double m) {
-    double s[3];
-    hydro_speed_from_cons(G, U, s);
-    for (int d = 0; d < dim; ++d) m = std_max(m, s[d]);
-    return m;
-}
-// Plasma5::get_allowed_time_step MFP_plasma5.cpp:535-555
-CMFP_DEV double cell_plasma_dt(double Larmor, double Debye, double Bx, double By, double Bz, double rho, double r, double dt) {
-    const double PI = 3.141592653589793;  // acos(-1)
-    const double D2 = Debye * Debye;
-    const double B = sqrt(Bx * Bx + By * By + Bz * Bz);
-    const double omega_p = 10 * sqrt(rho * r * r / D2) / (2 * PI);
-    if (omega_p > 0) dt = std_min(dt, 1 / omega_p);
-    const double omega_c = 10 * (fabs(r) * B) / (Larmor * 2 * PI);
-    if (omega_c > 0) dt = std_min(dt, 1 / omega_c);
-    return dt;
 }
 
 // fused form of one Strang source stage with the RK2 inner integrator
@@ -1247,6 +1180,12 @@ template <int NS> static void l_source_rk2_n(const Geo& g, const SourceArgs& a, 
         if (a.limits_dt) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, a.part_dt, (int)nb, 0, a.out_dt);
     }
 }
+static void l_source_coef(const SourceArgs& a, double dt, double out[3]) {
+    const SourceCoef k = source_coef(a, dt);
+    out[0] = k.f1;
+    out[1] = k.f2;
+    out[2] = k.f3;
+}
 static int l_source_fused(const Geo& g, const SourceArgs& a, double dt, int reduce, hipStream_t st) {
     switch (a.n_species) {
     case 1: l_source_rk2_n<1>(g, a, dt, reduce, st); break;
@@ -1357,6 +1296,8 @@ int ctu_fused(const Geo&, const StatePhys&, const double* Uin, double* Uout, int
 CMFP_GATHER_DECL(1) CMFP_GATHER_DECL(2) CMFP_GATHER_DECL(3)
 #undef CMFP_GATHER_DECL
 // defined in mfp_field3d.hip
+int ctu_field_src(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt, const int touches[3][2],
+                  const SourceEpi& epi, int part, hipStream_t);
 int ctu_field3d(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, double* DU, int do_ctu, double dt,
                 const int touches[3][2], hipStream_t);
 static int l_ctu_gather(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
@@ -1402,7 +1343,7 @@ const Launchers* launchers() {
     static const Launchers L = {l_prim,      l_recon,         l_face_bc,        l_fluxes,          l_correct,
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack,
-                                ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
+                                ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, ctu_field_src, l_source_coef, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
                                 l_leaf_prim2cons, l_reduce_final, l_new_dt};
     return &L;
 }

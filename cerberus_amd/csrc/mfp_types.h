@@ -104,6 +104,15 @@ struct SourceArgs {
     CollArgs coll;  // a collisions_rambo action over the same species, evaluated with this source (fused step)
 };
 
+// Strang source stage C evaluated by the last CTU kernel of the step (the field's) on the cells it updates
+struct SourceEpi {
+    int ns;             // species (1 or 2)
+    SourceArgs a;       // sp_U: the species' new-time data, already updated by their CTU kernels; f_U unused
+    double kf[3];       // SourceCoef of the half step (host-side dt; recomputed with a device-resident dt)
+    unsigned long long* red_speed[4];  // 256 slots each: max a + |u_d| of what was written (bits of a positive double)
+    unsigned long long* red_dt;        // 256 slots: min plasma / cyclotron dt (all-ones = empty)
+};
+
 // ghost fill rule per component for one (dim, side)
 enum FillRule { FILL_SKIP = 0, FILL_WRAP = 1, FILL_FOEXTRAP = 2, FILL_EVEN = 3, FILL_ODD = 4 };
 struct FillRules {
@@ -166,6 +175,11 @@ struct Launchers {
     // two-pass z-marching update of a 3-D field state (mfp_field3d.hip); F1: sweep-1 flux scratch
     int (*ctu_field3d)(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, double* DU, int do_ctu, double dt,
                        const int touches[3][2], hipStream_t);
+    // the tiled 2-D field update with the explicit Strang source stage C as its epilogue (mfp_fused.hip)
+    int (*ctu_field_src)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
+                         const int touches[3][2], const SourceEpi& epi, int part, hipStream_t);
+    // the three factors of MFP_plasma5.cpp:123-129 as the source kernels compute them on the host
+    void (*source_coef)(const SourceArgs&, double dt, double out[3]);
     // batched leaves
     int (*leaf_reconstruct)(int recon, long n, const double* st, double* slope, double* lo, double* hi, hipStream_t);
     int (*leaf_riemann)(int flux, long n, const double* L, const double* R, double* F, double c0, double ch,
