@@ -534,3 +534,29 @@ def test_field3d_tiles(oracle, recon, walls):
         for s in range(3):
             assert np.array_equal(m.download(s), ref.get_state(s)), (recon, walls, fused, P.state_names[s])
         m.close()
+
+
+# ---- Strang stage C as the epilogue of the tiled field kernel (mfp_fused.hip) ----------------------
+@pytest.mark.parametrize("name,make", [
+    ("ot_plasma5", lambda: problems.orszag_tang_two_fluid_2d(48)),
+    ("ot_lorentz", lambda: problems.orszag_tang_two_fluid_2d(48, source="Lorentz")),
+    ("gem_walls", lambda: problems.gem_reconnection_2d(48, 34)),
+])
+def test_source_epilogue(oracle, monkeypatch, name, make):
+    """the trailing source half step evaluated inside the field's CTU kernel (one source launch per
+    step instead of two) leaves the same bits as the separate launch and as the oracle, dt included"""
+    P = config.Problem(make(), fp_mode=abi.FP_STRICT)
+    ref = oracle.OracleSim(P)
+    dts_ref = ref.run(4)
+    for epilogue in (True, False):
+        monkeypatch.setenv("CMFP_SRC_EPILOGUE", "1" if epilogue else "0")
+        m = _gpu(P)
+        m.profile_enable(True)
+        m.profile_read(2)
+        dts = m.run(4)
+        launches, _ = m.profile_read(2)
+        assert launches == (4 if epilogue else 8), (name, epilogue, launches)
+        assert dts == dts_ref, (name, epilogue)
+        for s in range(len(P.state_names)):
+            assert np.array_equal(m.download(s), ref.get_state(s)), (name, epilogue, P.state_names[s])
+        m.close()
