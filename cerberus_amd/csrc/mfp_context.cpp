@@ -610,7 +610,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
                                                      nullptr, 0 | tile_flag, c->stream)) {
                     tiled[A.states[i]] = 1;
                 } else if (c->fused == 1 && c->L->ctu_field3d(c->g, sp, nullptr, nullptr, none, nullptr, A.corner_transport, dt, c->touches,
-                                                              c->stream)) {
+                                                              nullptr, c->stream)) {
                     f3d[A.states[i]] = 1;  // 3-D field: LDS plane-tile kernels (they use the F1 scratch and one F2 array)
                     any_gather = true;
                 } else if (c->L->ctu_gather(c->g, sp, nullptr, nullptr, none, none, A.corner_transport, dt, c->touches,
@@ -648,7 +648,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     if (src >= 0 && coll < 0 && c->src_epilogue && c->fused == 1) {
         const cmfp_action_desc& SA = c->actions[src];
         const int fs = SA.states[SA.n_states - 1];
-        bool ok = SA.n_states - 1 <= 2 && tiled[fs] && c->states[fs].sp.kind == CMFP_STATE_FIELD &&
+        bool ok = SA.n_states - 1 <= 2 && (tiled[fs] || f3d[fs]) && c->states[fs].sp.kind == CMFP_STATE_FIELD &&
                   !(SA.kind == CMFP_ACTION_PLASMA5 && SA.solver == CMFP_SOLVER_IMPLICIT);
         for (size_t q = 0; q < list.size(); ++q)
             if (list[q] == fs) epi_q = (int)q;
@@ -661,7 +661,10 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         if (ok) {
             epi.ns = SA.n_states - 1;
             epi.a = source_args(c, SA, true);
-            ok = c->L->ctu_field_src(c->g, c->states[fs].sp, nullptr, nullptr, ctu_flag[epi_q], dt, c->touches, epi, 0, c->stream) != 0;
+            ok = f3d[fs] ? c->L->ctu_field3d(c->g, c->states[fs].sp, nullptr, nullptr, none, nullptr, ctu_flag[epi_q], dt, c->touches,
+                                             &epi, c->stream) != 0
+                         : c->L->ctu_field_src(c->g, c->states[fs].sp, nullptr, nullptr, ctu_flag[epi_q], dt, c->touches, epi, 0,
+                                               c->stream) != 0;
         }
         if (!ok) epi_q = -1;
     }
@@ -737,13 +740,14 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     for (size_t q : order) {
         StateRT& s = c->states[list[q]];
         ProfScope prof(c, slot_of(s), c->stream, !overlap);
-        if ((int)q == epi_q)
+        if ((int)q == epi_q && !f3d[list[q]])
             c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, overlap ? 2 : 0, c->stream);
         else if (tiled[list[q]])
             c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], (overlap ? 2 : 0) | tile_flag,
                             c->stream);
         else if (f3d[list[q]])
-            c->L->ctu_field3d(c->g, s.sp, s.new_data, s.alt, F1, c->gF2[0], ctu_flag[q], dt, c->touches, c->stream);
+            c->L->ctu_field3d(c->g, s.sp, s.new_data, s.alt, F1, c->gF2[0], ctu_flag[q], dt, c->touches, (int)q == epi_q ? &epi : nullptr,
+                              c->stream);
         else
             c->L->ctu_gather(c->g, s.sp, s.new_data, s.alt, F1, F2, ctu_flag[q], dt, c->touches, c->d_err, slots[q], c->stream);
     }

@@ -23,6 +23,7 @@
 // halos), F1 and dU_xy written once and read once or twice.  Same device functions and operation order
 // per value: STRICT results are bit-identical to the oracle and the gather kernels.
 #include "mfp_march.h"
+#include "mfp_source.h"
 
 namespace CMFP_NS {
 
@@ -249,9 +250,11 @@ __global__ __launch_bounds__(256, 2) void k_f3d_xy(Geo g, FieldParams P, const d
 // -------------------------------------------------------------------------------------- z direction
 // Thread (tx, tz) of tile (tix, tiz): cell i = lo + 16 tix + tx, k = 14 tiz - 1 + tz; the workgroup marches
 // along y.  Faces k (between k - 1 and k) are computed by tz >= 1, cells are updated by tz in [1, 14].
-template <int RECON, int PASS, bool HAS_BC>
-__global__ __launch_bounds__(256, 3) void k_f3d_z(Geo g, FieldParams P, const double* __restrict__ Uin, double* __restrict__ Uout,
-                                                   Ptr3 F1, const double* __restrict__ DU, double dt, FaceBC3f bc, SelF3 sel) {
+// SRC > 0 (pass 2): the explicit Strang source stage C of SRC species on the cells just updated (see mfp_source.h)
+template <int RECON, int PASS, bool HAS_BC, int SRC = 0>
+__global__ __launch_bounds__(256, SRC > 0 ? 2 : 3) void k_f3d_z(Geo g, FieldParams P, const double* __restrict__ Uin, double* __restrict__ Uout,
+                                                   Ptr3 F1, const double* __restrict__ DU, double dt, FaceBC3f bc, SelF3 sel,
+                                                   typename EpiArg<SRC>::type epi) {
     constexpr int H = ReconTraits<RECON>::SL / 2, BX = 16, NPZ = (16 + 2 * H) * BX, C = 256;
     __shared__ double Pz[10][NPZ];
     __shared__ double bufR[10][C];
@@ -277,6 +280,9 @@ __global__ __launch_bounds__(256, 3) void k_f3d_z(Geo g, FieldParams P, const do
     const long base = g.at(ic, 0, kc);
     const long sx = 1, sy = g.sj;
     const bool face = tz >= 1 && k <= n2;
+    double src_speed[SRC > 0 ? SRC : 1], src_dt = DBL_MAX;
+#pragma unroll
+    for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s) src_speed[s] = DBL_MIN;
 
     for (int j = ja; j <= jb; ++j) {
         const long c = base + (long)j * sy;
@@ -326,6 +332,7 @@ __global__ __launch_bounds__(256, 3) void k_f3d_z(Geo g, FieldParams P, const do
             for (int n = 0; n < 8; ++n) bufR[n][tid] = F[n];
             __syncthreads();
             if (tz >= 1 && tz <= 14 && k < n2 && i < n0) {
+                double Unew[10];
 #pragma unroll
                 for (int n = 0; n < 10; ++n) {
                     double d = 0.0;
@@ -337,10 +344,17 @@ __global__ __launch_bounds__(256, 3) void k_f3d_z(Geo g, FieldParams P, const do
                         d += dtdy * (0.0 - 0.0);
                         d += dtdz * (0.0 - 0.0);
                     }
-                    Uout[c + n * g.sc] = Pz[n][pc] + d;  // the tile holds Uin
+                    Unew[n] = Pz[n][pc] + d;  // the tile holds Uin
                 }
+                if constexpr (SRC > 0) source_epilogue_cell<SRC>(g, epi, dt, c, Unew, src_speed, src_dt);
+#pragma unroll
+                for (int n = 0; n < 10; ++n) Uout[c + n * g.sc] = Unew[n];
             }
         }
+    }
+    if constexpr (SRC > 0) {
+        __syncthreads();  // the buffer is free
+        source_epilogue_reduce<SRC>(epi, src_speed, src_dt, &bufR[0][0], tid, C / 64, wg & 255);
     }
 }
 
@@ -364,7 +378,7 @@ static SelF3 make_sel(int nx, int tw, int ny, int np, int lo) {
 
 template <int RECON>
 static int launch_f3d(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, double* DU, double dt,
-                      const int touches[3][2], hipStream_t st) {
+                      const int touches[3][2], const SourceEpi* epi, hipStream_t st) {
     constexpr int H = ReconTraits<RECON>::SL / 2;
     if (g.ng[0] < H + 1 || g.ng[1] < H + 1 || g.ng[2] < H + 1) return 0;
     if (!Uin) return 1;  // coverage probe
@@ -386,28 +400,36 @@ static int launch_f3d(const Geo& g, const StatePhys& sp, const double* Uin, doub
     const SelF3 a = make_sel(n0 + 2, 14, n1 + 2, n2 + 2, -1);
     hipLaunchKernelGGL((k_f3d_xy<RECON, 1, false>), grid(a), block, 0, st, g, sp.fp, Uin, F1, DU, dt, bc, a);
     const SelF3 b = make_sel(n0 + 2, 16, n2 + 1, n1 + 2, -1);
-    hipLaunchKernelGGL((k_f3d_z<RECON, 1, false>), grid(b), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, b);
+    hipLaunchKernelGGL((k_f3d_z<RECON, 1, false>), grid(b), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, b, NoEpi{});
     // pass 2: the valid cells
     const SelF3 c = make_sel(n0, 14, n1, n2, 0);
     const SelF3 d = make_sel(n0, 16, n2, n1, 0);
-    if (has_bc) {
+    if (has_bc)
         hipLaunchKernelGGL((k_f3d_xy<RECON, 2, true>), grid(c), block, 0, st, g, sp.fp, Uin, F1, DU, dt, bc, c);
-        hipLaunchKernelGGL((k_f3d_z<RECON, 2, true>), grid(d), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, d);
-    } else {
+    else
         hipLaunchKernelGGL((k_f3d_xy<RECON, 2, false>), grid(c), block, 0, st, g, sp.fp, Uin, F1, DU, dt, bc, c);
-        hipLaunchKernelGGL((k_f3d_z<RECON, 2, false>), grid(d), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, d);
+#define F3Z(BC, NS, E) hipLaunchKernelGGL((k_f3d_z<RECON, 2, BC, NS>), grid(d), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, d, E)
+    if (epi && epi->ns == 2) {
+        if (has_bc) F3Z(true, 2, *epi); else F3Z(false, 2, *epi);
+    } else if (epi && epi->ns == 1) {
+        if (has_bc) F3Z(true, 1, *epi); else F3Z(false, 1, *epi);
+    } else {
+        if (has_bc) F3Z(true, 0, NoEpi{}); else F3Z(false, 0, NoEpi{});
     }
+#undef F3Z
     return 1;
 }
 
 // Update of a 3-D field state from LDS plane tiles; F1: sweep-1 flux scratch, DU: dU_xy scratch (8 planes
-// each).  Returns 0 where the option set is outside these kernels (the caller then uses the gather kernels).
+// each); epi (may be null): the explicit Strang source stage C as the epilogue of the last launch.
+// Returns 0 where the option set is outside these kernels (the caller then uses the gather kernels).
 int ctu_field3d(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, double* DU, int do_ctu,
-                double dt, const int touches[3][2], hipStream_t st) {
+                double dt, const int touches[3][2], const SourceEpi* epi, hipStream_t st) {
     if (g.dim != 3 || sp.kind != 1 || !do_ctu || sp.flux != 10) return 0;
-    if (sp.recon == 5) return launch_f3d<5>(g, sp, Uin, Uout, F1, DU, dt, touches, st);
-    if (sp.recon == 1) return launch_f3d<1>(g, sp, Uin, Uout, F1, DU, dt, touches, st);
-    if (sp.recon == 2) return launch_f3d<2>(g, sp, Uin, Uout, F1, DU, dt, touches, st);
+    if (epi && (epi->a.implicit || epi->a.coll.on || epi->ns < 1 || epi->ns > 2)) return 0;
+    if (sp.recon == 5) return launch_f3d<5>(g, sp, Uin, Uout, F1, DU, dt, touches, epi, st);
+    if (sp.recon == 1) return launch_f3d<1>(g, sp, Uin, Uout, F1, DU, dt, touches, epi, st);
+    if (sp.recon == 2) return launch_f3d<2>(g, sp, Uin, Uout, F1, DU, dt, touches, epi, st);
     return 0;
 }
 

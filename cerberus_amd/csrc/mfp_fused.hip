@@ -83,11 +83,6 @@ __device__ __forceinline__ void tile_of(const TileSel& s, int t, int& tix, int& 
     }
 }
 
-// kernel argument of the source epilogue (SRC species; nothing without one)
-struct NoEpi {};
-template <int SRC> struct EpiArg { typedef SourceEpi type; };
-template <> struct EpiArg<0> { typedef NoEpi type; };
-
 // SRC > 0 (field states): the explicit Strang source stage C (k_source_rk2's arithmetic) of SRC species is
 // applied to the cells this kernel updates, with the CFL reductions of what it writes.
 template <class Phys, int BX, int BY, bool HAS_BC, bool REDUCE, int SRC = 0>
@@ -360,36 +355,7 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
         if constexpr (SRC > 0) {
             // Strang stage C on this cell (MFP_advance.cpp:235-281): the species were updated by their own
             // CTU kernels before this launch; in place on their new-time data
-            const SourceArgs& a = epi.a;
-            const double hdt = 0.5 * dt;
-            SourceCoef kf{epi.kf[0], epi.kf[1], epi.kf[2]};
-            if (g.dtp) kf = source_coef(a, hdt);
-            double s0[SRC][5], snew[SRC][4], fnew[5];
-#pragma unroll
-            for (int s = 0; s < SRC; ++s)
-#pragma unroll
-                for (int n = 0; n < 5; ++n) s0[s][n] = a.sp_U[s][c + n * g.sc];
-            source_rk2_explicit_cell<SRC>(a, kf, hdt, Unew, s0, fnew, snew);
-#pragma unroll
-            for (int s = 0; s < SRC; ++s) {
-                double Un[5];
-                Un[0] = s0[s][0];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    Un[n + 1] = snew[s][n];
-                    a.sp_U[s][c + (n + 1) * g.sc] = snew[s][n];
-                }
-                GasP G{1.0, 0.0, a.gamma[s]};
-                src_speed[s] = cell_max_speed(G, Un, g.dim, src_speed[s]);
-                if (a.limits_dt) src_dt = cell_plasma_dt(a.Larmor, a.Debye, Unew[F_BX], Unew[F_BY], Unew[F_BZ], Un[0], a.r[s], src_dt);
-            }
-            if (!a.lorentz_only) {
-                Unew[F_DX] = fnew[0];
-                Unew[F_DY] = fnew[1];
-                Unew[F_DZ] = fnew[2];
-                Unew[F_PHI] = fnew[3];
-                Unew[F_PSI] = fnew[4];
-            }
+            source_epilogue_cell<SRC>(g, epi, dt, c, Unew, src_speed, src_dt);
 #pragma unroll
             for (int n = 0; n < NC; ++n) Uout[c + n * g.sc] = Unew[n];
         }
@@ -418,31 +384,8 @@ __global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g,
         }
     }
     if constexpr (SRC > 0) {
-        // the reductions k_source_rk2<REDUCE> leaves: wave, workgroup (LDS), one integer atomic per word
-        double* const shr = bufR;  // free since the barrier that ended phase 4
-#pragma unroll
-        for (int s = 0; s < SRC; ++s)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) src_speed[s] = fmax(src_speed[s], __shfl_xor(src_speed[s], o, 64));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) src_dt = fmin(src_dt, __shfl_xor(src_dt, o, 64));
-        if ((tid & 63) == 0) {
-#pragma unroll
-            for (int s = 0; s < SRC; ++s) shr[(tid >> 6) * 4 + s] = src_speed[s];
-            shr[(tid >> 6) * 4 + 3] = src_dt;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w2 = 1; w2 < C / 64; ++w2) {
-#pragma unroll
-                for (int s = 0; s < SRC; ++s) src_speed[s] = fmax(src_speed[s], shr[w2 * 4 + s]);
-                src_dt = fmin(src_dt, shr[w2 * 4 + 3]);
-            }
-#pragma unroll
-            for (int s = 0; s < SRC; ++s)
-                atomicMax(&epi.red_speed[s][tile & 255], (unsigned long long)__double_as_longlong(src_speed[s]));
-            if (epi.a.limits_dt) atomicMin(&epi.red_dt[tile & 255], (unsigned long long)__double_as_longlong(src_dt));
-        }
+        // the reductions k_source_rk2<REDUCE> leaves (bufR is free since the barrier that ended phase 4)
+        source_epilogue_reduce<SRC>(epi, src_speed, src_dt, bufR, tid, C / 64, tile & 255);
     }
     STAMP(10);
 }

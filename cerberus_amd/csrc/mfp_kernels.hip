@@ -1299,7 +1299,7 @@ CMFP_GATHER_DECL(1) CMFP_GATHER_DECL(2) CMFP_GATHER_DECL(3)
 int ctu_field_src(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt, const int touches[3][2],
                   const SourceEpi& epi, int part, hipStream_t);
 int ctu_field3d(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, double* DU, int do_ctu, double dt,
-                const int touches[3][2], hipStream_t);
+                const int touches[3][2], const SourceEpi* epi, hipStream_t);
 static int l_ctu_gather(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
                         int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
     if (g.dim == 1) return ctu_gather_1(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);

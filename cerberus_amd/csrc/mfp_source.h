@@ -116,4 +116,76 @@ CMFP_DEV void source_rk2_explicit_cell(const SourceArgs& a, const SourceCoef& kf
     fnew[4] = 0.5 * f0[F_PSI] + 0.5 * (f1[F_PSI] + fdU[4]);
 }
 
+// kernel argument of the source epilogue (SRC species; nothing without one)
+struct NoEpi {};
+template <int SRC> struct EpiArg { typedef SourceEpi type; };
+template <> struct EpiArg<0> { typedef NoEpi type; };
+
+// Stage C on one updated cell of the field's CTU kernel: Unew = the field after its CTU update (in/out),
+// the species are read from and written to their new-time arrays at offset c; the CFL quantities of what
+// was written are folded into src_speed / src_dt (k_source_rk2<REDUCE>).
+template <int NS>
+CMFP_DEV void source_epilogue_cell(const Geo& g, const SourceEpi& epi, double dt, long c, double* Unew, double* src_speed,
+                                   double& src_dt) {
+    const SourceArgs& a = epi.a;
+    const double hdt = 0.5 * dt;
+    SourceCoef kf{epi.kf[0], epi.kf[1], epi.kf[2]};
+    if (g.dtp) kf = source_coef(a, hdt);
+    double s0[NS][5], snew[NS][4], fnew[5];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int n = 0; n < 5; ++n) s0[s][n] = a.sp_U[s][c + n * g.sc];
+    source_rk2_explicit_cell<NS>(a, kf, hdt, Unew, s0, fnew, snew);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double Un[5];
+        Un[0] = s0[s][0];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            Un[n + 1] = snew[s][n];
+            a.sp_U[s][c + (n + 1) * g.sc] = snew[s][n];
+        }
+        GasP G{1.0, 0.0, a.gamma[s]};
+        src_speed[s] = cell_max_speed(G, Un, g.dim, src_speed[s]);
+        if (a.limits_dt) src_dt = cell_plasma_dt(a.Larmor, a.Debye, Unew[F_BX], Unew[F_BY], Unew[F_BZ], Un[0], a.r[s], src_dt);
+    }
+    if (!a.lorentz_only) {
+        Unew[F_DX] = fnew[0];
+        Unew[F_DY] = fnew[1];
+        Unew[F_DZ] = fnew[2];
+        Unew[F_PHI] = fnew[3];
+        Unew[F_PSI] = fnew[4];
+    }
+}
+
+// workgroup reduction of the epilogue's CFL quantities and one integer atomic per word on slot `slot`;
+// shr: >= 4 doubles per wave of LDS nobody else uses any more; every thread of the workgroup calls it
+template <int NS>
+CMFP_DEV void source_epilogue_reduce(const SourceEpi& epi, double* src_speed, double src_dt, double* shr, int tid, int nwaves,
+                                     int slot) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) src_speed[s] = fmax(src_speed[s], __shfl_xor(src_speed[s], o, 64));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) src_dt = fmin(src_dt, __shfl_xor(src_dt, o, 64));
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) shr[(tid >> 6) * 4 + s] = src_speed[s];
+        shr[(tid >> 6) * 4 + 3] = src_dt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w2 = 1; w2 < nwaves; ++w2) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) src_speed[s] = fmax(src_speed[s], shr[w2 * 4 + s]);
+            src_dt = fmin(src_dt, shr[w2 * 4 + 3]);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) atomicMax(&epi.red_speed[s][slot], (unsigned long long)__double_as_longlong(src_speed[s]));
+        if (epi.a.limits_dt) atomicMin(&epi.red_dt[slot], (unsigned long long)__double_as_longlong(src_dt));
+    }
+}
+
 }  // namespace CMFP_NS

@@ -174,7 +174,7 @@ struct Launchers {
                       int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t);
     // two-pass z-marching update of a 3-D field state (mfp_field3d.hip); F1: sweep-1 flux scratch
     int (*ctu_field3d)(const Geo&, const StatePhys&, const double* Uin, double* Uout, const Ptr3& F1, double* DU, int do_ctu, double dt,
-                       const int touches[3][2], hipStream_t);
+                       const int touches[3][2], const SourceEpi* epi, hipStream_t);
     // the tiled 2-D field update with the explicit Strang source stage C as its epilogue (mfp_fused.hip)
     int (*ctu_field_src)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
                          const int touches[3][2], const SourceEpi& epi, int part, hipStream_t);

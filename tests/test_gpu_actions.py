@@ -541,6 +541,7 @@ def test_field3d_tiles(oracle, recon, walls):
     ("ot_plasma5", lambda: problems.orszag_tang_two_fluid_2d(48)),
     ("ot_lorentz", lambda: problems.orszag_tang_two_fluid_2d(48, source="Lorentz")),
     ("gem_walls", lambda: problems.gem_reconnection_2d(48, 34)),
+    ("rmi_3d", lambda: problems.richtmyer_meshkov_3d(20, 17, 40)),
 ])
 def test_source_epilogue(oracle, monkeypatch, name, make):
     """the trailing source half step evaluated inside the field's CTU kernel (one source launch per
