@@ -5,7 +5,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
-B3="python3 $R/bench.py --workload rmi_3d --n 256 --steps 4 --warmup 1 --no-cpu-baseline"
+B3="python3 $R/bench.py --workload rmi_3d --cells 256 --steps 4 --warmup 1 --no-cpu-baseline"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ot_stats -o ot -- $B > $R/gpurun_out/prof_ot_stats.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_ot_fetch -o ot -- $B > $R/gpurun_out/prof_ot_fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_ot_write -o ot -- $B > $R/gpurun_out/prof_ot_write.log 2>&1
