@@ -78,6 +78,8 @@ struct cmfp_context {
     int touches[3][2];   // block face is a non-periodic physical boundary
     int split[3];        // domain is split between ranks along d
     cmfp_exchange_fn exchange = nullptr;
+    cmfp_dt_reduce_fn dt_reduce = nullptr;
+    void* dt_reduce_user = nullptr;
     void* exchange_user = nullptr;
     int exchange_batched = 0;
     int src_epilogue = 1;      // Strang stage C inside the field's CTU kernel where that applies (CMFP_SRC_EPILOGUE=0: never)
@@ -1193,8 +1195,9 @@ int cmfp_advance_steps(cmfp_context* c, double, double dt0, int nsteps, double* 
     if ((r = check_ctx(c))) return r;
     if (nsteps < 1 || !dts || !dt_next) return fail(c, CMFP_ERR_INVALID, "bad arguments");
     if (!c->fused) return 1;
-    for (int d = 0; d < c->g.dim; ++d)
-        if (c->split[d]) return 1;  // the cross-rank dt reduction needs the host: per-step API
+    bool split_any = false;
+    for (int d = 0; d < c->g.dim; ++d) split_any = split_any || c->split[d];
+    if (split_any && !c->dt_reduce) return 1;  // the cross-rank dt minimum needs a callback, else the per-step API
     const int ns = (int)c->states.size(), na = (int)c->actions.size();
     DtPlan plan;
     std::memset(&plan, 0, sizeof(plan));
@@ -1255,6 +1258,11 @@ int cmfp_advance_steps(cmfp_context* c, double, double dt0, int nsteps, double* 
                 c->red_valid[ns + a] = 1;
             }
         c->L->new_dt(plan, c->d_red, d_dt, d_log, i, c->stream);
+        if (split_any && c->dt_reduce(c->dt_reduce_user, c, d_dt)) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            cleanup();
+            return fail(c, CMFP_ERR_INVALID, "dt reduce callback failed");
+        }
     }
     c->g.dtp = nullptr;
     e = hipMemcpyAsync(dts, d_log, sizeof(double) * (size_t)nsteps, hipMemcpyDeviceToHost, c->stream);
@@ -1361,6 +1369,21 @@ int cmfp_set_exchange_callback(cmfp_context* c, cmfp_exchange_fn fn, void* user)
 int cmfp_set_overlap(cmfp_context* c, int mode) {
     if (!c || mode < 0 || mode > 2) return CMFP_ERR_INVALID;
     c->overlap = mode;
+    return CMFP_OK;
+}
+
+int cmfp_set_dt_reduce_callback(cmfp_context* c, cmfp_dt_reduce_fn fn, void* user) {
+    if (!c) return CMFP_ERR_INVALID;
+    c->dt_reduce = fn;
+    c->dt_reduce_user = user;
+    return CMFP_OK;
+}
+
+int cmfp_copy_async(cmfp_context* c, void* dst, const void* src, long long nbytes) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (!dst || !src || nbytes < 0) return fail(c, CMFP_ERR_INVALID, "bad arguments");
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, c->stream));
     return CMFP_OK;
 }
 

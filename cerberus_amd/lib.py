@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libcerberus_mfp.so")
 
 dp = C.POINTER(C.c_double)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+DT_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 
 # every symbol include/cerberus_mfp.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -44,6 +45,8 @@ SYMBOLS = [
     ("cmfp_profile_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), dp]),
     ("cmfp_set_exchange_callback", C.c_int, [C.c_void_p, EXCHANGE_FN, C.c_void_p]),
     ("cmfp_set_exchange_batched", C.c_int, [C.c_void_p, C.c_int]),
+    ("cmfp_set_dt_reduce_callback", C.c_int, [C.c_void_p, DT_REDUCE_FN, C.c_void_p]),
+    ("cmfp_copy_async", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]),
     ("cmfp_set_overlap", C.c_int, [C.c_void_p, C.c_int]),
     ("cmfp_fill_patch", C.c_int, [C.c_void_p, C.c_int]),
     ("cmfp_halo_count", C.c_longlong, [C.c_void_p, C.c_int, C.c_int]),

@@ -71,7 +71,7 @@ class MFP:
         self._chk(self.L.cmfp_set_overlap(self.h, int(overlap)))
         self.shape = tuple(self.block_n[::-1])
         self.time, self.dt, self.step = 0.0, None, 0
-        self._device_dt = bool(device_dt) and world == 1
+        self._device_dt = bool(device_dt)
         self._time_bc = [s for s in range(self.n_states) if p.face_values_depend_on_time(s)]
         if self._time_bc and p.scheme != "strang":
             raise NotImplementedError("time-dependent boundary functions: 'strang' only (one flux evaluation at t + dt)")
@@ -84,6 +84,11 @@ class MFP:
             self._cb = lib.EXCHANGE_FN(self._exchange)
             self._chk(self.L.cmfp_set_exchange_callback(self.h, self._cb, None))
             self._chk(self.L.cmfp_set_exchange_batched(self.h, int(batched_exchange)))
+            if self._device_dt:
+                # cmfp_advance_steps on split blocks: the cross-rank dt minimum stays on the device
+                self._dt_cb = lib.DT_REDUCE_FN(self._dt_reduce)
+                self._dt_buf = None
+                self._chk(self.L.cmfp_set_dt_reduce_callback(self.h, self._dt_cb, None))
 
     # ------------------------------------------------------------------
     def _chk(self, rc):
@@ -286,6 +291,30 @@ class MFP:
     def _pack_device(self):
         import torch
         return torch.device("cuda", torch.cuda.current_device())
+
+    def _dt_reduce(self, user, ctx, ptr):
+        """cmfp_dt_reduce_fn: all-reduce(MIN) of the device-resident dt (ReduceRealMin, MFP_timestep.cpp:18),
+        enqueued in stream order: no host synchronisation with RCCL."""
+        try:
+            import torch
+            import torch.distributed as dist
+            if self._dt_buf is None:
+                self._dt_buf = torch.empty(1, dtype=torch.float64, device=self._pack_device())
+            buf = self._dt_buf
+            self._chk(self.L.cmfp_copy_async(self.h, C.c_void_p(buf.data_ptr()), C.c_void_p(ptr), 8))
+            if self._exchange_device is not None and torch.device(self._exchange_device) != buf.device:
+                h = buf.to(self._exchange_device)     # host-staged transport (gloo)
+                dist.all_reduce(h, op=dist.ReduceOp.MIN, group=self.pg)
+                buf.copy_(h)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.MIN, group=self.pg)
+            self._chk(self.L.cmfp_copy_async(self.h, C.c_void_p(ptr), C.c_void_p(buf.data_ptr()), 8))
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            self._exchange_error = e
+            return 1
 
     def _exchange(self, user, ctx, s, d):
         """cmfp_exchange_fn: pack both faces, swap with the neighbours, unpack.

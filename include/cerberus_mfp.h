@@ -314,6 +314,17 @@ int cmfp_set_exchange_batched(cmfp_context* ctx, int on);
  * callback must only enqueue work on, or synchronise with, the context's stream. */
 int cmfp_set_overlap(cmfp_context* ctx, int mode);
 int cmfp_fill_patch(cmfp_context* ctx, int state);
+/* Cross-rank time-step minimum for cmfp_advance_steps: the ParallelDescriptor::ReduceRealMin of
+ * MFP::estTimeStep (MFP_timestep.cpp:18), without the host.  After each step's device-side
+ * computeNewDt the library calls fn with the device address of the double holding this rank's next
+ * dt; fn must replace it, in stream order on the context's stream, by the minimum over all ranks
+ * (e.g. an RCCL all-reduce(MIN) of one double).  min_r min(cfl*est_r, 1.1*dt) = min(cfl*min_r est_r,
+ * 1.1*dt): the reference's value.  With a callback registered cmfp_advance_steps also runs on blocks
+ * that are split between ranks.  cmfp_copy_async moves a few bytes device-to-device on the context's
+ * stream (for bindings whose collectives need their own buffer). */
+typedef int (*cmfp_dt_reduce_fn)(void* user, cmfp_context* ctx, double* device_dt);
+int cmfp_set_dt_reduce_callback(cmfp_context* ctx, cmfp_dt_reduce_fn fn, void* user);
+int cmfp_copy_async(cmfp_context* ctx, void* dst, const void* src, long long nbytes);
 /* Number of doubles in one packed face of `state` normal to `dim`. */
 long long cmfp_halo_count(const cmfp_context* ctx, int state, int dim);
 /* side 0: pack the ng valid layers next to the low face (to send to the low

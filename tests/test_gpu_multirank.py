@@ -29,7 +29,7 @@ def _worker(rank, world, port, which, batched, ret):
         m = MFP(P, device=0, rank=rank, world=world, exchange_device="cpu", batched_exchange=batched)
         m.init_data()
         dts = m.run(5)
-        out = {"dts": dts, "lo": m.block_lo, "n": m.block_n, "fused": m.last_advance_fused(),
+        out = {"dts": dts, "lo": m.block_lo, "n": m.block_n, "fused": m.last_advance_fused(), "device_dt": m._device_dt,
                "data": [m.download(s) for s in range(m.n_states)]}
         ret[rank] = out
         m.close()
@@ -90,7 +90,50 @@ def test_decomposed_run_equals_single_rank(world, which, batched):
         o = ret[r]
         assert o["dts"] == dts
         assert o["fused"] == (which != "inflow")
+        assert o["device_dt"] == (which != "inflow")     # cmfp_advance_steps with the cross-rank dt minimum on the device
         lo, n = o["lo"], o["n"]
         for s in range(len(full)):
             ref = full[s][:, lo[2]:lo[2] + n[2], lo[1]:lo[1] + n[1], lo[0]:lo[0] + n[0]]
             assert np.array_equal(o["data"][s], ref), (r, s)
+
+
+def _nccl_worker(port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from cerberus_amd import abi, config, problems
+    from cerberus_amd.mfp import MFP
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        P = config.Problem(problems.kelvin_helmholtz_2d(32), fp_mode=abi.FP_STRICT)
+        m = MFP(P, device=0, rank=0, world=1)
+        m.world = 2                      # only to take the RCCL branch of the hooks below
+        m._exchange_device = None
+        m._dt_buf = None
+        word = torch.tensor([0.125], dtype=torch.float64, device="cuda")
+        rc = m._dt_reduce(None, None, word.data_ptr())
+        torch.cuda.synchronize()
+        ret["rc"], ret["value"] = rc, float(word.item())
+        m.world = 1
+        m.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dt_reduce_hook_on_rccl():
+    """the device-side dt minimum of cmfp_advance_steps through torch.distributed's RCCL backend
+    (one rank: the collective is the identity, the plumbing is what is checked)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), ret))
+    p.start()
+    p.join(120)
+    if p.is_alive():
+        p.terminate()
+        pytest.fail("RCCL worker hung")
+    assert p.exitcode == 0
+    assert ret["rc"] == 0 and ret["value"] == 0.125
