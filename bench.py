@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse", action="store_true",
                     help="diagnostic: run the N-rank path on ONE GPU (all ranks on cuda:0, gloo with host-staged halos); not a measurement")
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2],
+                    help="diagnostic: cmfp_set_overlap mode (2 = interior / frame split launches even on an unsplit block)")
     ap.add_argument("--no-corner-transport", action="store_true", help="diagnostic: corner_transport=false (not the headline workload)")
     args = ap.parse_args()
 
@@ -148,7 +150,7 @@ def main():
     grid = block_grid(dim, world)
     P = build_problem(args.workload, args.n, grid, fp_mode, not args.no_corner_transport)
     m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=(3 if args.tiled_hydro else not args.no_fused),
-            exchange_device=("cpu" if args.rehearse and world > 1 else None))
+            exchange_device=("cpu" if args.rehearse and world > 1 else None), overlap=args.overlap)
     m.init_data()
 
     def sync():
