@@ -21,10 +21,18 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES = {"ot2f_2d": 320, "kh_2d": 80, "rmi_3d": 320}   # 2 x 8 B x Ncomp per cell-update
+ALGO_BYTES = {"ot2f_2d": 320, "kh_2d": 80, "rmi_3d": 320, "gem_2d": 320}   # 2 x 8 B x Ncomp per cell-update
 WORKLOAD_NOTE = {"ot2f_2d": "BASELINE configs[2]: 2D two-fluid Orszag-Tang, plasma5 source",
                  "kh_2d": "BASELINE configs[1]: 2D KH hydro HLLC",
-                 "rmi_3d": "BASELINE configs[4]: 3D two-fluid Richtmyer-Meshkov, plasma5 source"}
+                 "rmi_3d": "BASELINE configs[4]: 3D two-fluid Richtmyer-Meshkov, plasma5 source",
+                 "gem_2d": "BASELINE configs[3]: 2D GEM reconnection two-fluid + Maxwell, walls in y; 8 GPUs x 4096x2048 = 8192^2"}
+
+
+def block_cells(workload, n):
+    """cells of the per-GPU block: n per side; GEM blocks are n x n/2 (2 x 4 of them make the 8192^2 domain)"""
+    if workload == "gem_2d":
+        return [n, n // 2]
+    return [n] * (3 if workload == "rmi_3d" else 2)
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -36,6 +44,8 @@ def build_problem(workload, n, grid, fp_mode, corner_transport=True):
         cfg = problems.kelvin_helmholtz_2d(n)
     elif workload == "rmi_3d":
         cfg = problems.richtmyer_meshkov_3d(n)
+    elif workload == "gem_2d":
+        cfg = problems.gem_reconnection_2d(n, n // 2)
     else:
         raise SystemExit(f"unknown workload {workload}")
     if not corner_transport:
@@ -44,9 +54,10 @@ def build_problem(workload, n, grid, fp_mode, corner_transport=True):
                 a["corner_transport"] = False
     # weak scaling: the domain grows with the process grid, dx and the per-GPU block stay fixed
     # (both initial conditions are periodic with the single-GPU domain length)
+    blk = block_cells(workload, n)
     for d in range(cfg["dim"]):
         L = cfg["prob_hi"][d] - cfg["prob_lo"][d]
-        cfg["n_cell"][d] = n * grid[d]
+        cfg["n_cell"][d] = blk[d] * grid[d]
         cfg["prob_hi"][d] = cfg["prob_lo"][d] + L * grid[d]
     return config.Problem(cfg, fp_mode=fp_mode)
 
@@ -177,7 +188,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
 
-    cells_per_gpu = args.n ** dim
+    blk = block_cells(args.workload, args.n)
+    cells_per_gpu = 1
+    for v in blk:
+        cells_per_gpu *= v
     total_cells = cells_per_gpu * world
     value = total_cells * args.steps / el
 
@@ -214,7 +228,7 @@ def main():
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload} {'x'.join([str(args.n)] * dim)} per GPU ({WORKLOAD_NOTE[args.workload]})",
+            "config": {"workload": f"{args.workload} {'x'.join(str(v) for v in blk)} per GPU ({WORKLOAD_NOTE[args.workload]})",
                        "process_grid": grid[:dim], "global_cells": list(P.n_cell[:dim]), "fp_mode": args.fp,
                        "fused_kernels": bool(fused), "corner_transport": not args.no_corner_transport, "time_integration": P.scheme, "cfl": P.cfl},
             "hbm_roofline_frac_whole_step": (step_bytes * args.steps / (el)) / 1e9 / HBM_PEAK_GBS,
