@@ -84,3 +84,23 @@ def test_device_resident_dt_equals_per_step_calls(case):
         assert np.array_equal(a.download(s), b.download(s)), (name, P.state_names[s])
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg,steps", small_cases(), ids=[c[0] for c in small_cases()])
+def test_strict_gpu_matches_committed_nstep_vectors(name, cfg, steps):
+    """STRICT HIP path against the committed N-step vectors (tests/golden/oracle_nstep.json): dt sequence
+    and every conserved value bit for bit, without the oracle in the loop"""
+    import hashlib
+    import json
+    import os
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_nstep.json")))[name]
+    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    m = _gpu(P)
+    dts = m.run(G["steps"])
+    assert [float(v).hex() for v in dts] == G["dts"]
+    for s, sname in enumerate(P.state_names):
+        a = np.ascontiguousarray(m.download(s), dtype=np.float64)
+        assert list(a.shape) == G["states"][sname]["shape"]
+        assert hashlib.sha256(a.tobytes()).hexdigest() == G["states"][sname]["sha256"], (name, sname)
+    m.close()

@@ -295,3 +295,20 @@ def test_inflow_face_imposes_the_profile(oracle):
         cfg = inflow_cfg()
         del cfg["states"]["fluid"]["bc"]["x"]["lo"]["p"]
         config.Problem(cfg).face_entries(0)
+
+
+# ---- committed N-step vectors (tests/golden/oracle_nstep.json, tools/make_golden_nstep.py) ----------
+@pytest.mark.parametrize("name,cfg,steps", small_cases(), ids=[c[0] for c in small_cases()])
+def test_oracle_reproduces_committed_nstep_vectors(oracle, name, cfg, steps):
+    """the restatement's N-step result (dt sequence and every conserved value, bit for bit) is the one
+    committed with the repository: orchestration, ghost fill and integrator order cannot drift silently"""
+    import hashlib
+    G = json.load(open(os.path.join(HERE, "golden", "oracle_nstep.json")))[name]
+    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    sim = oracle.OracleSim(P)
+    dts = sim.run(G["steps"])
+    assert [float(v).hex() for v in dts] == G["dts"]
+    for s, sname in enumerate(P.state_names):
+        a = np.ascontiguousarray(sim.get_state(s), dtype=np.float64)
+        assert list(a.shape) == G["states"][sname]["shape"]
+        assert hashlib.sha256(a.tobytes()).hexdigest() == G["states"][sname]["sha256"], (name, sname)
