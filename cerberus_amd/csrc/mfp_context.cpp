@@ -628,12 +628,6 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             if ((r = dalloc(c, &c->gF1[d], 8 * c->g.sc))) return r;
             if ((r = dalloc(c, &c->gF2[d], 8 * c->g.sc))) return r;
         }
-    if (src >= 0) {
-        SourceArgs a = source_args(c, c->actions[src], true);
-        if (coll >= 0) a.coll = coll_args(c, c->actions[coll]);
-        ProfScope prof(c, CMFP_PROF_SOURCE);
-        if (!c->L->source_fused(c->g, a, 0.5 * dt, 0, c->stream)) return 0;
-    }
     std::vector<int> list;  // every state a CTU action updates, with its action's corner_transport flag
     std::vector<int> ctu_flag;
     for (const auto& A : c->actions)
@@ -642,6 +636,65 @@ int advance_strang_fused(cmfp_context* c, double dt) {
                 list.push_back(A.states[i]);
                 ctu_flag.push_back(A.corner_transport);
             }
+    // Will the flux launches be split into interior and frame (see below)?  If the block is split between
+    // ranks and they will not (3-D: the marching kernels take the whole block), stage A is split instead:
+    // the frame of cells within ng of a face first - every ghost fill reads only those - then the interior
+    // on a second stream while the ghost layers are packed, exchanged and unpacked.
+    bool split_any = false;
+    for (int d = 0; d < c->g.dim; ++d) split_any = split_any || c->split[d];
+    bool overlap = c->overlap == 2 || (c->overlap == 1 && split_any);
+    for (size_t q = 0; q < list.size() && overlap; ++q)
+        overlap = tiled[list[q]] && c->L->ctu_fused(c->g, c->states[list[q]].sp, nullptr, nullptr, ctu_flag[q], dt, c->touches,
+                                                    nullptr, nullptr, 1 | tile_flag, c->stream);
+    bool src_split = false;
+    if ((overlap || (src >= 0 && split_any && c->overlap != 0)) && !c->stream2) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming));
+    }
+    if (src >= 0) {
+        SourceArgs a = source_args(c, c->actions[src], true);
+        if (coll >= 0) a.coll = coll_args(c, c->actions[coll]);
+        IBox inner;
+        bool has_inner = !overlap && split_any && c->overlap != 0;
+        for (int d = 0; d < 3; ++d) {
+            const int w = d < c->g.dim ? c->g.ng[d] : 0;
+            inner.lo[d] = w;
+            inner.hi[d] = c->g.n[d] - 1 - w;
+            has_inner = has_inner && (d >= c->g.dim || inner.hi[d] >= inner.lo[d]);
+        }
+        if (has_inner) {
+            // frame: slabs peeled off dimension by dimension (disjoint), on the main stream
+            IBox rest;
+            for (int d = 0; d < 3; ++d) {
+                rest.lo[d] = 0;
+                rest.hi[d] = c->g.n[d] - 1;
+            }
+            {
+                ProfScope prof(c, CMFP_PROF_SOURCE);
+                for (int d = c->g.dim - 1; d >= 0; --d) {
+                    IBox lo_slab = rest, hi_slab = rest;
+                    lo_slab.hi[d] = inner.lo[d] - 1;
+                    hi_slab.lo[d] = inner.hi[d] + 1;
+                    if (!c->L->source_fused_box(c->g, a, 0.5 * dt, lo_slab, c->stream)) return 0;
+                    if (!c->L->source_fused_box(c->g, a, 0.5 * dt, hi_slab, c->stream)) return 0;
+                    rest.lo[d] = inner.lo[d];
+                    rest.hi[d] = inner.hi[d];
+                }
+            }
+            HIPCHK(c, hipEventRecord(c->ev_src, c->stream));  // everything of the previous step, and the frame
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_src, 0));
+            {
+                ProfScope prof(c, CMFP_PROF_SOURCE, c->stream2, false);
+                c->L->source_fused_box(c->g, a, 0.5 * dt, inner, c->stream2);
+            }
+            HIPCHK(c, hipEventRecord(c->ev_int, c->stream2));
+            src_split = true;
+        } else {
+            ProfScope prof(c, CMFP_PROF_SOURCE);
+            if (!c->L->source_fused(c->g, a, 0.5 * dt, 0, c->stream)) return 0;
+        }
+    }
     // Strang stage C as the epilogue of the field's CTU kernel (the last launch of the step): explicit
     // plasma5 / Lorentz over species that are all CTU states, 2-D tiled field kernel
     int epi_q = -1;
@@ -673,17 +726,6 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     // Halo/compute overlap: where the block is split between ranks, the flux update of the tiles
     // whose stencils stay inside valid cells runs on a second stream while the ghost layers are
     // packed, exchanged and unpacked on the main one; the frame of boundary tiles follows the fill.
-    bool split_any = false;
-    for (int d = 0; d < c->g.dim; ++d) split_any = split_any || c->split[d];
-    bool overlap = c->overlap == 2 || (c->overlap == 1 && split_any);
-    for (size_t q = 0; q < list.size() && overlap; ++q)
-        overlap = tiled[list[q]] && c->L->ctu_fused(c->g, c->states[list[q]].sp, nullptr, nullptr, ctu_flag[q], dt, c->touches,
-                                                    nullptr, nullptr, 1 | tile_flag, c->stream);
-    if (overlap && !c->stream2) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming));
-    }
     std::vector<unsigned long long*> slots(list.size(), nullptr);
     for (size_t q = 0; q < list.size(); ++q) {
         StateRT& s = c->states[list[q]];
@@ -739,6 +781,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         int r;
         if ((r = fill_patch_many(c, list))) return r;
     }
+    if (src_split) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_int, 0));  // interior of stage A
     for (size_t q : order) {
         StateRT& s = c->states[list[q]];
         ProfScope prof(c, slot_of(s), c->stream, !overlap);

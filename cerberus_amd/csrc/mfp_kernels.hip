@@ -1158,8 +1158,9 @@ static void l_collisions(const Geo& g, const SourceArgs& a, double dt, hipStream
 }
 static unsigned red_blocks(long npts) { return (unsigned)std::min<long>(nblocks(npts), RED_BLOCKS); }
 
-template <int NS> static void l_source_rk2_n(const Geo& g, const SourceArgs& a, double dt, int reduce, hipStream_t st) {
-    IBox b = valid_box(g);
+template <int NS> static void l_source_rk2_n(const Geo& g, const SourceArgs& a, double dt, int reduce, hipStream_t st,
+                                             const IBox* sub = nullptr) {
+    IBox b = sub ? *sub : valid_box(g);
     const unsigned nb = red_blocks(b.npts());
     const SourceCoef kf = source_coef(a, dt);
 #define RK2(I, R, C) hipLaunchKernelGGL((k_source_rk2<NS, I, R, C>), dim3(nb), dim3(TPB), 0, st, g, b, a, kf, dt)
@@ -1185,6 +1186,19 @@ static void l_source_coef(const SourceArgs& a, double dt, double out[3]) {
     out[0] = k.f1;
     out[1] = k.f2;
     out[2] = k.f3;
+}
+// the same stage on a sub-box of the valid cells (no reductions): stage A split into the frame the ghost
+// fills read and the interior, so that the interior overlaps the halo exchange
+static int l_source_fused_box(const Geo& g, const SourceArgs& a, double dt, const IBox& box, hipStream_t st) {
+    if (box.npts() <= 0) return 1;
+    switch (a.n_species) {
+    case 1: l_source_rk2_n<1>(g, a, dt, 0, st, &box); break;
+    case 2: l_source_rk2_n<2>(g, a, dt, 0, st, &box); break;
+    case 3: l_source_rk2_n<3>(g, a, dt, 0, st, &box); break;
+    case 4: l_source_rk2_n<4>(g, a, dt, 0, st, &box); break;
+    default: return 0;
+    }
+    return 1;
 }
 static int l_source_fused(const Geo& g, const SourceArgs& a, double dt, int reduce, hipStream_t st) {
     switch (a.n_species) {
@@ -1343,7 +1357,7 @@ const Launchers* launchers() {
     static const Launchers L = {l_prim,      l_recon,         l_face_bc,        l_fluxes,          l_correct,
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack,
-                                ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, ctu_field_src, l_source_coef, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
+                                ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, ctu_field_src, l_source_coef, l_source_fused_box, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
                                 l_leaf_prim2cons, l_reduce_final, l_new_dt};
     return &L;
 }

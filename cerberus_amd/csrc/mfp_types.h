@@ -180,6 +180,8 @@ struct Launchers {
                          const int touches[3][2], const SourceEpi& epi, int part, hipStream_t);
     // the three factors of MFP_plasma5.cpp:123-129 as the source kernels compute them on the host
     void (*source_coef)(const SourceArgs&, double dt, double out[3]);
+    // source_fused on a sub-box of the valid cells, without reductions
+    int (*source_fused_box)(const Geo&, const SourceArgs&, double dt, const IBox& box, hipStream_t);
     // batched leaves
     int (*leaf_reconstruct)(int recon, long n, const double* st, double* slope, double* lo, double* hi, hipStream_t);
     int (*leaf_riemann)(int flux, long n, const double* L, const double* R, double* F, double c0, double ch,

@@ -309,7 +309,9 @@ int cmfp_set_exchange_batched(cmfp_context* ctx, int on);
 /* Halo/compute overlap inside cmfp_advance (fused 2-D Strang step).  1 (default): where the block is
  * split between ranks, the flux update of the interior tiles runs on a second, library-owned stream
  * while the ghost layers are packed, exchanged (callback) and unpacked on the context's stream; the
- * frame of boundary tiles follows the fill.  0: one launch per state after the fill.  2: split the
+ * frame of boundary tiles follows the fill.  Where the flux launches are not split (3-D, or no interior
+ * tiles) the first source half step is: the cells within ng of a face first, the interior on the second
+ * stream while the ghost layers travel.  0: one launch per state after the fill.  2: split the
  * launches even on an unsplit block (testing).  Results are identical in all modes.  The exchange
  * callback must only enqueue work on, or synchronise with, the context's stream. */
 int cmfp_set_overlap(cmfp_context* ctx, int mode);

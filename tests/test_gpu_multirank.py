@@ -49,7 +49,9 @@ def _cfg(which):
         return inflow_cfg(32, 16)
     if which == "gem":
         return problems.gem_reconnection_2d(32, 32)
-    return problems.richtmyer_meshkov_3d(16, 16, 16)     # 3-D: gather kernels, 1x2x2 blocks
+    if which == "rmi3d24":      # 12^3 blocks: stage A split into frame and interior (the interior overlaps the exchange)
+        return problems.richtmyer_meshkov_3d(12, 24, 24)
+    return problems.richtmyer_meshkov_3d(16, 16, 16)     # 3-D, 1x2x2 blocks of 16x8x8
 
 
 def _free_port():
@@ -61,7 +63,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,which,batched", [(2, "ot", True), (4, "ot", True), (4, "ot", False), (4, "gem", True), (4, "ot96", True), (2, "ot96", False),
-                                                 (4, "rmi3d", True), (4, "inflow", True), (2, "inflow", False)])
+                                                 (4, "rmi3d", True), (4, "rmi3d24", True), (2, "rmi3d24", False), (4, "inflow", True), (2, "inflow", False)])
 def test_decomposed_run_equals_single_rank(world, which, batched):
     import torch.multiprocessing as mp
     from cerberus_amd import abi, config, problems
