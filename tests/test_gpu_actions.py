@@ -508,12 +508,14 @@ def test_march3d_hydro(oracle, recon, flux, walls):
 
 
 # ---- 3-D field update from LDS plane tiles (mfp_field3d.hip) ---------------------------------------
-@pytest.mark.parametrize("recon,walls", [("O6", False), ("O6", True), ("vanLeer", True), ("minmod", True)])
-def test_field3d_tiles(oracle, recon, walls):
+@pytest.mark.parametrize("recon,walls,n", [("O6", False, (20, 17, 40)), ("O6", True, (20, 17, 40)), ("vanLeer", True, (20, 17, 40)),
+                                           ("minmod", True, (20, 17, 40)), ("O6", True, (28, 14, 30)), ("O6", False, (29, 15, 33)),
+                                           ("O6", True, (6, 4, 9)), ("O6", False, (16, 32, 14))])
+def test_field3d_tiles(oracle, recon, walls, n):
     """two-fluid + Maxwell 3-D block on the plane-tile field kernels: partial tiles in every direction,
     several marching segments, conducting walls / outflow on all six faces of the field: bit-identical
     to the oracle and to the gather kernels."""
-    cfg = problems.richtmyer_meshkov_3d(20, 17, 40)
+    cfg = problems.richtmyer_meshkov_3d(*n)     # tile edges: multiples of 14 / 16, one more, and blocks below one tile
     cfg["states"]["field"]["reconstruction"] = recon
     if walls:
         cfg["is_periodic"] = [0, 0, 0]
