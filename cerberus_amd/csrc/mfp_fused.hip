@@ -86,7 +86,7 @@ __device__ __forceinline__ void tile_of(const TileSel& s, int t, int& tix, int& 
 // SRC > 0 (field states): the explicit Strang source stage C (k_source_rk2's arithmetic) of SRC species is
 // applied to the cells this kernel updates, with the CFL reductions of what it writes.
 template <class Phys, int BX, int BY, bool HAS_BC, bool REDUCE, int SRC = 0>
-__global__ __launch_bounds__(BX* BY, Phys::IS_HYDRO ? 4 : 3) void k_ctu2d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
+__global__ __launch_bounds__(BX* BY, (Phys::IS_HYDRO ? 1024 : 768) / (BX * BY)) void k_ctu2d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
                                                    double* __restrict__ Uout, int do_ctu, double dt, FaceBC bc, int* err,
                                                    TileSel sel, unsigned long long* red, typename EpiArg<SRC>::type epi) {
     constexpr int NQ = Phys::NQ, NC = Phys::NC, NF = Phys::NF, RECON = Phys::RECON;
