@@ -647,6 +647,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         overlap = tiled[list[q]] && c->L->ctu_fused(c->g, c->states[list[q]].sp, nullptr, nullptr, ctu_flag[q], dt, c->touches,
                                                     nullptr, nullptr, 1 | tile_flag, c->stream);
     bool src_split = false;
+    IBox src_inner;
     if ((overlap || (src >= 0 && split_any && c->overlap != 0)) && !c->stream2) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
@@ -684,12 +685,8 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             }
             HIPCHK(c, hipEventRecord(c->ev_src, c->stream));  // everything of the previous step, and the frame
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_src, 0));
-            {
-                ProfScope prof(c, CMFP_PROF_SOURCE, c->stream2, false);
-                c->L->source_fused_box(c->g, a, 0.5 * dt, inner, c->stream2);
-            }
-            HIPCHK(c, hipEventRecord(c->ev_int, c->stream2));
             src_split = true;
+            src_inner = inner;
         } else {
             ProfScope prof(c, CMFP_PROF_SOURCE);
             if (!c->L->source_fused(c->g, a, 0.5 * dt, 0, c->stream)) return 0;
@@ -781,7 +778,18 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         int r;
         if ((r = fill_patch_many(c, list))) return r;
     }
-    if (src_split) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_int, 0));  // interior of stage A
+    if (src_split) {
+        // the interior of stage A goes to the device after the packs and the exchange have been enqueued:
+        // its long-lived workgroups must not keep the transfer kernels waiting for a place on the CUs
+        SourceArgs a = source_args(c, c->actions[src], true);
+        if (coll >= 0) a.coll = coll_args(c, c->actions[coll]);
+        {
+            ProfScope prof(c, CMFP_PROF_SOURCE, c->stream2, false);
+            c->L->source_fused_box(c->g, a, 0.5 * dt, src_inner, c->stream2);
+        }
+        HIPCHK(c, hipEventRecord(c->ev_int, c->stream2));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_int, 0));
+    }
     for (size_t q : order) {
         StateRT& s = c->states[list[q]];
         ProfScope prof(c, slot_of(s), c->stream, !overlap);
