@@ -222,16 +222,27 @@ int fill_patch_many(cmfp_context* c, const std::vector<int>& list) {
     const Geo& g = c->g;
     ProfScope prof(c, CMFP_PROF_FILL);
     for (int d = 0; d < g.dim; ++d) {
+        // both sides of up to four states per launch (sides and states are independent of each other)
+        FillJobs J;
+        J.n = 0;
+        auto flush = [&]() {
+            if (J.n) c->L->fill_multi(g, d, J, c->stream);
+            J.n = 0;
+        };
         for (int si : list) {
             StateRT& s = c->states[si];
+            FillJob& f = J.j[J.n];
+            f.A = s.new_data;
+            f.nc = s.sp.nc;
+            f.ngs = s.sp.ng;
             for (int side = 0; side < 2; ++side) {
-                if (!c->split[d])
-                    c->L->fill_dim(g, s.sp.nc, s.sp.ng, s.new_data, d, side,
-                                   c->geom.is_periodic[d] ? wrap_rules(s) : bc_rules(s, d, side), c->stream);
-                else if (c->touches[d][side])
-                    c->L->fill_dim(g, s.sp.nc, s.sp.ng, s.new_data, d, side, bc_rules(s, d, side), c->stream);
+                f.on[side] = !c->split[d] || c->touches[d][side];
+                f.rules[side] = (!c->split[d] && c->geom.is_periodic[d]) ? wrap_rules(s) : bc_rules(s, d, side);
             }
+            if (f.on[0] || f.on[1]) ++J.n;
+            if (J.n == 4) flush();
         }
+        flush();
         if (!c->split[d]) continue;
         if (!c->exchange) return fail(c, CMFP_ERR_INVALID, "domain is split along a dimension but no exchange callback is set");
         if (c->exchange_batched) {

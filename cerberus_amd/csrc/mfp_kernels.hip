@@ -898,9 +898,29 @@ __global__ void k_plasma_dt(Geo g, IBox box, SourceArgs a, double* part) {
 // ------------------------------------------------------------------ ghosts
 // One (dim, side) sweep of the ghost fill: fab_filcc semantics (dimension by
 // dimension over the full extent of the other dimensions) + periodic wrap.
+__device__ __forceinline__ void fill_dim_cell(const Geo& g, const IBox& slab, long t, int nc, int d, int side, const FillRules& rules,
+                                              double* __restrict__ A);
 __global__ void k_fill_dim(Geo g, IBox slab, int nc, int ngs, int d, int side, FillRules rules, double* __restrict__ A) {
+    fill_dim_cell(g, slab, (long)blockIdx.x * TPB + threadIdx.x, nc, d, side, rules, A);
+}
+// blockIdx.y = 2 * job + side
+__global__ void k_fill_multi(Geo g, int d, FillJobs J) {
+    const int job = (int)blockIdx.y >> 1, side = (int)blockIdx.y & 1;
+    const FillJob& f = J.j[job];
+    if (!f.on[side]) return;
+    IBox slab;
+    for (int t = 0; t < 3; ++t) {
+        slab.lo[t] = -g.ng[t];
+        slab.hi[t] = g.n[t] - 1 + g.ng[t];
+    }
+    slab.lo[d] = 1;
+    slab.hi[d] = f.ngs;
+    fill_dim_cell(g, slab, (long)blockIdx.x * TPB + threadIdx.x, f.nc, d, side, f.rules[side], f.A);
+}
+__device__ __forceinline__ void fill_dim_cell(const Geo& g, const IBox& slab, long t, int nc, int d, int side, const FillRules& rules,
+                                              double* __restrict__ A) {
     int c3[3];
-    if (!decode(slab, (long)blockIdx.x * TPB + threadIdx.x, c3[0], c3[1], c3[2])) return;
+    if (!decode(slab, t, c3[0], c3[1], c3[2])) return;
     // slab coordinate along d is the layer 1..ngs
     const int layer = c3[d];
     const int n = g.n[d];
@@ -1256,6 +1276,12 @@ static void l_fill_dim(const Geo& g, int nc, int ngs, double* A, int d, int side
     IBox s = ghost_slab(g, d, ngs, 1);
     LAUNCH(k_fill_dim, s.npts(), st, g, s, nc, ngs, d, side, rules, A);
 }
+static void l_fill_multi(const Geo& g, int d, const FillJobs& J, hipStream_t st) {
+    long npts = 0;
+    for (int k = 0; k < J.n; ++k) npts = std::max(npts, ghost_slab(g, d, J.j[k].ngs, 1).npts());
+    if (J.n <= 0 || npts <= 0) return;
+    hipLaunchKernelGGL(k_fill_multi, dim3(nblocks(npts), 2 * J.n), dim3(TPB), 0, st, g, d, J);
+}
 static void l_pack(const Geo& g, int nc, int ngs, double* A, int d, int side, double* buf, int unpack, hipStream_t st) {
     IBox s = ghost_slab(g, d, ngs, 1);
     int first;
@@ -1356,7 +1382,7 @@ static void l_reduce_final(const double* part, int n, int is_max, unsigned long 
 const Launchers* launchers() {
     static const Launchers L = {l_prim,      l_recon,         l_face_bc,        l_fluxes,          l_correct,
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
-                                l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack,
+                                l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack, l_fill_multi,
                                 ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, ctu_field_src, l_source_coef, l_source_fused_box, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
                                 l_leaf_prim2cons, l_reduce_final, l_new_dt};
     return &L;

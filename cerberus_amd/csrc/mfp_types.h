@@ -119,6 +119,18 @@ struct FillRules {
     int rule[10];
 };
 
+// One launch of the ghost fill of dimension d for several states and both sides (k_fill_multi)
+struct FillJob {
+    double* A;
+    int nc, ngs;
+    int on[2];          // side switched on
+    FillRules rules[2];
+};
+struct FillJobs {
+    int n;
+    FillJob j[4];
+};
+
 // What MFP::estTimeStep combines (MFP_timestep.cpp:4-21), for the device-side step control
 struct DtPlan {
     int n;
@@ -163,6 +175,8 @@ struct Launchers {
     // ghosts
     void (*fill_dim)(const Geo&, int nc, int ngs, double* A, int d, int side, FillRules, hipStream_t);
     void (*pack)(const Geo&, int nc, int ngs, double* A, int d, int side, double* buf, int unpack, hipStream_t);
+    // fill_dim of up to four states and both sides in one launch (the sides and states are independent)
+    void (*fill_multi)(const Geo&, int d, const FillJobs&, hipStream_t);
     // fused paths (return 0 when the option set is not covered)
     int (*ctu_fused)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
                      const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t);
