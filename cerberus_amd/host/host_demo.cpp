@@ -6,12 +6,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 using namespace mfp;
 
 int main(int argc, char** argv) {
     const int n = argc > 1 ? std::atoi(argv[1]) : 32;
     const int steps = argc > 2 ? std::atoi(argv[2]) : 5;
+    const bool batch = argc > 3 && std::string(argv[3]) == "batch";
     const double gam = 5.0 / 3.0, c = 20.0, PI = std::acos(-1.0), L = 2 * PI;
     try {
         MFP level;
@@ -81,11 +83,17 @@ int main(int argc, char** argv) {
             level.check(cmfp_state_upload(level.ctx, (int)s, U.data()));
         }
         double t = 0, dt = level.estTimeStep();
-        for (int k = 0; k < steps; ++k) {
-            level.advance(t, dt);
-            t += dt;
-            std::printf("dt %.17g\n", dt);
-            dt = level.computeNewDt(dt);
+        if (batch) {  // the whole loop enqueued at once, dt on the device
+            std::vector<Real> dts;
+            level.advance_steps(t, dt, steps, dts);
+            for (Real v : dts) std::printf("dt %.17g\n", v);
+        } else {
+            for (int k = 0; k < steps; ++k) {
+                level.advance(t, dt);
+                t += dt;
+                std::printf("dt %.17g\n", dt);
+                dt = level.computeNewDt(dt);
+            }
         }
         for (size_t s = 0; s < level.states.size(); ++s) {
             const int nc = (int)level.eulerian(s).n_cons();

@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cpp_host_demo_matches_python_driver():
+@pytest.mark.parametrize("mode", [[], ["batch"]], ids=["per_step", "advance_steps"])
+def test_cpp_host_demo_matches_python_driver(mode):
     from cerberus_amd.mfp import MFP
     exe = os.path.join(ROOT, "cerberus_amd", "host", "host_demo")
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
-    out = subprocess.run([exe, "32", "5"], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, "32", "5"] + mode, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     dts = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("dt ")]
     sums = {l.split()[1]: (float(l.split()[3]), float(l.split()[5])) for l in out.stdout.splitlines() if l.startswith("state ")}
