@@ -56,7 +56,7 @@ traffic = {"_comment": "HBM bytes per launch from separate rocprofv3 --pmc passe
                        "WRITE_SIZE*1024.  Written by tools/summarize_profiles.py."}
 entry = {}
 for tag, sub, ncomp in (("ctu_hydro", "k_ctu_march<", 5), ("ctu_hydro_tiled", "k_ctu2d<fast::HydroF", 5),
-                        ("ctu_field", "k_ctu2d<fast::FieldF", 10), ("source_rk2", "k_source_rk2<2, false, true", 20)):
+                        ("ctu_field", "k_ctu2d<fast::FieldF", 10), ("source_rk2", "k_source_rk2<2, false, ", 20)):
     k = pick(sub)
     if not k:
         continue
@@ -65,6 +65,8 @@ for tag, sub, ncomp in (("ctu_hydro", "k_ctu_march<", 5), ("ctu_hydro_tiled", "k
     entry[tag + "_fetch_bytes"] = int(rd)
     entry[tag + "_write_bytes"] = int(wr)
     entry[tag + "_bytes_per_launch"] = int(rd + wr)
+    if tag == "ctu_field" and ", 2>(" in k:   # field update with the source epilogue of two species: all 20 components
+        ncomp = 20
     entry[tag + "_algorithmic_bytes"] = 2 * 8 * ncomp * cells
 traffic[f"ot2f_2d:{n}"] = entry
 json.dump(traffic, open(os.path.join(os.path.dirname(out.rstrip("/")), os.path.basename(out.rstrip("/")) + "_traffic.json"), "w"), indent=2)
