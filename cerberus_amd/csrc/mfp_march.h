@@ -75,15 +75,18 @@ static inline bool march_select(const Geo& g, int part, int ring, int mw, int mu
         r.ilo = ilo, r.ihi = ihi, r.jlo = jlo, r.jhi = jhi;
         r.ns = (ihi - ilo + mw) / mw;
     };
+    // frame widths: at least the ghost reach; on blocks large enough a whole strip in x (no idle lanes in
+    // the two side columns) and 32 rows in y (the pipeline start-up of a wave is paid once per 32 rows)
+    const int fx = n0 >= 4 * mw ? mw : ring, fy = n1 >= 4 * 32 ? 32 : ring;
     if (part == 0 || (part == 2 && !has_int)) {
         add(0, n0 - 1, 0, n1 - 1);
     } else if (part == 1) {
-        add(ring, n0 - 1 - ring, ring, n1 - 1 - ring);
+        add(fx, n0 - 1 - fx, fy, n1 - 1 - fy);
     } else {
-        add(0, n0 - 1, 0, ring - 1);
-        add(0, n0 - 1, n1 - ring, n1 - 1);
-        add(0, ring - 1, ring, n1 - 1 - ring);
-        add(n0 - ring, n0 - 1, ring, n1 - 1 - ring);
+        add(0, n0 - 1, 0, fy - 1);
+        add(0, n0 - 1, n1 - fy, n1 - 1);
+        add(0, fx - 1, fy, n1 - 1 - fy);
+        add(n0 - fx, n0 - 1, fy, n1 - 1 - fy);
     }
     if (sel.nrect == 0) return false;
     // segment length: one resident round of waves where the block is large enough for segments of
