@@ -355,12 +355,12 @@ static int launch3d(const Geo& g, const typename Phys::Params& P, const StatePhy
     sel.gy = (g.n[1] + 13) / 14;
     // z-segments: enough workgroups to fill the device several times over (measured at 256^3: 16- to
     // 32-plane segments are best, 4.8 ms for two states; one segment per tile, 361 workgroups: 6.6 ms),
-    // at least 16 planes each
+    // at least 12 planes each (96^3: 12-plane segments beat 16 by 8 %; 128^3: no difference)
     const int tiles = sel.gx * sel.gy;
     int nseg = (2 * wave_slots() + tiles - 1) / tiles;  // wave_slots() / 4 workgroups are resident at 2 waves per SIMD: eight rounds
     if (nseg < 1) nseg = 1;
     int seg = (g.n[2] + nseg - 1) / nseg;
-    if (seg < 16) seg = 16;
+    if (seg < 12) seg = 12;
     static const int seg_env = std::getenv("CMFP_MARCH3D_SEG") ? std::atoi(std::getenv("CMFP_MARCH3D_SEG")) : 0;
     if (seg_env > 0) seg = seg_env;
     if (seg > g.n[2]) seg = g.n[2];
