@@ -75,9 +75,11 @@ static inline bool march_select(const Geo& g, int part, int ring, int mw, int mu
         r.ilo = ilo, r.ihi = ihi, r.jlo = jlo, r.jhi = jhi;
         r.ns = (ihi - ilo + mw) / mw;
     };
-    // frame widths: at least the ghost reach; on blocks large enough a whole strip in x (no idle lanes in
-    // the two side columns) and 32 rows in y (the pipeline start-up of a wave is paid once per 32 rows)
-    const int fx = n0 >= 4 * mw ? mw : ring, fy = n1 >= 4 * 32 ? 32 : ring;
+    // frame widths = the ghost reach.  They must not grow: the field's launch applies the source epilogue to
+    // its interior tiles on the second stream and reads the species there, so every cell of a field interior
+    // tile (>= 14 cells from the faces) has to lie in the hydro interior launched before it on that stream.
+    // (A strip-wide frame was 2.5 % faster and wrong for exactly that reason.)
+    const int fx = ring, fy = ring;
     if (part == 0 || (part == 2 && !has_int)) {
         add(0, n0 - 1, 0, n1 - 1);
     } else if (part == 1) {

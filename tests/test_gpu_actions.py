@@ -202,7 +202,7 @@ def test_marching_kernel_strips_segments_and_walls(oracle, flux, thr):
     default segment is >= 32 rows), sizes that are no multiple of either, slip walls on all four
     domain faces (update_face_prim on x and y faces), single and split launches: bit-identical to
     the oracle and to the tiled kernel."""
-    for n in ([61, 33], [125, 70], [180, 37], [250, 131]):   # the last one: strip-wide / 32-row frame rectangles
+    for n in ([61, 33], [125, 70], [180, 37], [250, 131]):
         cfg = _kh("vanLeer", flux, thr=thr, n=32)
         cfg["n_cell"] = n
         cfg["is_periodic"] = [0, 0]

@@ -41,6 +41,8 @@ def _cfg(which):
     from cerberus_amd import problems
     if which == "ot":
         return problems.orszag_tang_two_fluid_2d(32)
+    if which == "ot512":        # blocks of 512 x 256 / 256 x 256: several strips, segments and tile rows per rank
+        return problems.orszag_tang_two_fluid_2d(512)
     if which == "ot96":
         return problems.orszag_tang_two_fluid_2d(96)      # 48^2 blocks: interior tiles overlap the exchange
     if which == "inflow":       # Dirichlet face tables cut into the ranks' blocks (stage-by-stage kernels)
@@ -70,7 +72,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,which,batched", [(2, "ot", True), (4, "ot", True), (4, "ot", False), (4, "gem", True), (4, "ot96", True), (2, "ot96", False),
+@pytest.mark.parametrize("world,which,batched", [(2, "ot", True), (4, "ot", True), (4, "ot", False), (4, "gem", True), (4, "ot96", True), (2, "ot96", False), (2, "ot512", True), (4, "ot512", True),
                                                  (4, "rmi3d", True), (4, "rmi3d24", True), (2, "rmi3d24", False), (4, "inflow", True), (2, "inflow", False)] +
                                                 [(2 + 2 * (k % 2), f"rand{k}", k % 3 != 0) for k in range(10)])
 def test_decomposed_run_equals_single_rank(world, which, batched):
