@@ -720,6 +720,10 @@ int advance_strang_fused(cmfp_context* c, double dt) {
             bool in_list = false;
             for (int v : list) in_list = in_list || v == SA.states[n];
             ok = in_list && c->states[SA.states[n]].sp.kind == CMFP_STATE_HYDRO;
+            // split launches: the field's interior launch reads the species at its cells on the second stream,
+            // so its interior must lie inside every species' interior (launched before it on that stream):
+            // true when the species' stencils are no wider than the field's
+            if (overlap) ok = ok && c->states[SA.states[n]].sp.ng <= c->states[fs].sp.ng;
         }
         if (ok) {
             epi.ns = SA.n_states - 1;

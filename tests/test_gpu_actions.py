@@ -588,3 +588,28 @@ def test_source_epilogue(oracle, monkeypatch, name, make):
         for s in range(len(P.state_names)):
             assert np.array_equal(m.download(s), ref.get_state(s)), (name, epilogue, P.state_names[s])
         m.close()
+
+
+def test_source_epilogue_with_split_launches_and_mixed_stencils(oracle):
+    """forced split launches (overlap=2): with three-point species and an O6 field the field's interior
+    launch carries the source epilogue on the second stream (its interior lies inside the species'
+    interiors); with O6 species the hydro states leave the tiled kernels, nothing is split and the epilogue
+    follows whole launches.  Bit-identical to the oracle either way, one source launch per step."""
+    for hydro_recon, field_recon in (("O6", "minmod"), ("minmod", "O6"), ("vanLeer", "minmod")):
+        cfg = problems.orszag_tang_two_fluid_2d(96)
+        for name in ("ion", "electron"):
+            cfg["states"][name]["reconstruction"] = hydro_recon
+        cfg["states"]["field"]["reconstruction"] = field_recon
+        P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+        ref = oracle.OracleSim(P)
+        dts_ref = ref.run(3)
+        m = _gpu(P, overlap=2)
+        m.profile_enable(True)
+        m.profile_read(2)
+        dts = m.run(3)
+        launches, _ = m.profile_read(2)
+        assert launches == 3, (hydro_recon, field_recon, launches)
+        assert dts == dts_ref
+        for s in range(3):
+            assert np.array_equal(m.download(s), ref.get_state(s)), (hydro_recon, field_recon, P.state_names[s])
+        m.close()
