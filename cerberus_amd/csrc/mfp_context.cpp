@@ -85,7 +85,7 @@ struct cmfp_context {
     int src_epilogue = 1;      // Strang stage C inside the field's CTU kernel where that applies (CMFP_SRC_EPILOGUE=0: never)
     int overlap = 1;           // 1: interior flux tiles overlap the halo exchange where the block is split; 2: always split the launches
     hipStream_t stream2 = nullptr;  // interior tiles run here while ghost cells are in flight on `stream`
-    hipEvent_t ev_src = nullptr, ev_int = nullptr;  // one callback per dimension for all states (state = CMFP_ALL_STATES)
+    hipEvent_t ev_src = nullptr, ev_int = nullptr, ev_hyd = nullptr;  // one callback per dimension for all states (state = CMFP_ALL_STATES)
     int* d_err = nullptr;
     unsigned long long* d_red = nullptr;  // one reduction word per state + per action
     double* d_part = nullptr;             // CMFP_RED_BLOCKS block partials per word
@@ -663,6 +663,7 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_hyd, hipEventDisableTiming));
     }
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
@@ -779,6 +780,9 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_src, 0));
         for (size_t q : order) {
             StateRT& s = c->states[list[q]];
+            // the species' interiors are complete here (the epilogue field is last in `order`): the frame launch
+            // of that field on the main stream, whose tiles reach into the species' interiors, waits for this
+            if ((int)q == epi_q) HIPCHK(c, hipEventRecord(c->ev_hyd, c->stream2));
             ProfScope prof(c, slot_of(s), c->stream2, true);
             if ((int)q == epi_q)
                 c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, 1, c->stream2);
@@ -807,6 +811,9 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     }
     for (size_t q : order) {
         StateRT& s = c->states[list[q]];
+        // the frame tiles of the epilogue field read and rewrite species cells that the species' interior
+        // launches (second stream) update: wait for them
+        if (overlap && (int)q == epi_q) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_hyd, 0));
         ProfScope prof(c, slot_of(s), c->stream, !overlap);
         if ((int)q == epi_q && !f3d[list[q]])
             c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, overlap ? 2 : 0, c->stream);
@@ -1018,6 +1025,7 @@ int cmfp_destroy(cmfp_context* c) {
         (void)hipStreamDestroy(c->stream2);
         (void)hipEventDestroy(c->ev_src);
         (void)hipEventDestroy(c->ev_int);
+        if (c->ev_hyd) (void)hipEventDestroy(c->ev_hyd);
     }
     for (double* p : c->allocs) (void)hipFree(p);
     if (c->d_err) (void)hipFree(c->d_err);

@@ -298,6 +298,14 @@ def test_full_size_two_fluid_properties():
         assert dts == runs[0][0]
         for s in range(3):
             assert np.array_equal(data[s], runs[0][1][s]), s
+    # interior / frame split launches on two streams (what a rank of a decomposed run does), source epilogue
+    # included: same bits (the frame launch of the field must wait for the species' interior launches)
+    m = _gpu(P, overlap=2)
+    dts = m.run(3)
+    assert dts == runs[0][0]
+    for s in range(3):
+        assert np.array_equal(m.download(s), runs[0][1][s]), ("split launches", s)
+    m.close()
     data = runs[0][1]
     for s, name in enumerate(P.state_names):
         if name == "field":
