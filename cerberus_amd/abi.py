@@ -48,6 +48,7 @@ class Params(C.Structure):
         ("time_integrator", C.c_int),
         ("fp_mode", C.c_int),
         ("n0", C.c_double),
+        ("force_dt", C.c_double),
     ]
 
 

@@ -92,6 +92,7 @@ class Problem:
         self.ref = update_ref(cfg)
         self.cfl = float(cfg.get("cfl", DEFAULTS["cfl"]))
         self.scheme = cfg.get("time_integration_scheme", DEFAULTS["time_integration_scheme"])
+        self.force_dt = float(cfg.get("force_dt", DEFAULTS["force_dt"]))   # MFP_timestep.cpp:8
         self.fp_mode = fp_mode
         self.state_names = sorted(cfg["states"].keys())       # get_sorted_keys, MFP_config.cpp:102
         self.action_names = sorted(cfg.get("actions", {}).keys())  # :261
@@ -119,6 +120,7 @@ class Problem:
         p.time_integrator = abi.TIME_INTEGRATOR[self.scheme]
         p.fp_mode = self.fp_mode
         p.n0 = self.ref["n0"]
+        p.force_dt = self.force_dt
         return p
 
     def state_descs(self):

@@ -87,6 +87,8 @@ struct cmfp_context {
     hipStream_t stream2 = nullptr;  // interior tiles run here while ghost cells are in flight on `stream`
     hipEvent_t ev_src = nullptr, ev_int = nullptr, ev_hyd = nullptr;  // one callback per dimension for all states (state = CMFP_ALL_STATES)
     int* d_err = nullptr;
+    double* d_dtbuf = nullptr;  // cmfp_advance_steps: device-resident dt + dt log
+    int d_dtcap = 0;
     unsigned long long* d_red = nullptr;  // one reduction word per state + per action
     double* d_part = nullptr;             // CMFP_RED_BLOCKS block partials per word
     std::vector<char> red_valid;          // word already holds the reduction of the current new-time data
@@ -1029,6 +1031,7 @@ int cmfp_destroy(cmfp_context* c) {
     }
     for (double* p : c->allocs) (void)hipFree(p);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_dtbuf) (void)hipFree(c->d_dtbuf);
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->d_part) (void)hipFree(c->d_part);
     delete c;
@@ -1234,6 +1237,10 @@ int cmfp_est_time_step(cmfp_context* c, double* out) {
     int r;
     if ((r = check_ctx(c))) return r;
     if (!out) return fail(c, CMFP_ERR_INVALID, "null pointer");
+    if (c->params.force_dt > 0.0) {  // MFP_timestep.cpp:8
+        *out = c->params.force_dt;
+        return CMFP_OK;
+    }
     const int ns = (int)c->states.size(), na = (int)c->actions.size();
     std::vector<unsigned long long> h(2 * ns + na, 0);
     for (int s = 0; s < ns; ++s) {
@@ -1263,21 +1270,19 @@ double cmfp_compute_new_dt(double est_dt, double old_dt) {
     return std::min(est_dt, change_max * old_dt);
 }
 
-// nsteps x {MFP::advance; MFP::computeNewDt} with dt kept on the device (no host round trip per step)
-int cmfp_advance_steps(cmfp_context* c, double, double dt0, int nsteps, double* dts, double* dt_next) {
+// nsteps x {MFP::advance; MFP::computeNewDt} with dt kept on the device (no host round trip per step).
+// d_dt: 1 + nsteps doubles of device memory (the time step, then the log of the dt every step used).
+static int advance_steps_on(cmfp_context* c, double dt0, int nsteps, double* dts, double* dt_next, double* d_dt) {
     int r;
-    if ((r = check_ctx(c))) return r;
-    if (nsteps < 1 || !dts || !dt_next) return fail(c, CMFP_ERR_INVALID, "bad arguments");
-    if (!c->fused) return 1;
     bool split_any = false;
     for (int d = 0; d < c->g.dim; ++d) split_any = split_any || c->split[d];
-    if (split_any && !c->dt_reduce) return 1;  // the cross-rank dt minimum needs a callback, else the per-step API
     const int ns = (int)c->states.size(), na = (int)c->actions.size();
     DtPlan plan;
     std::memset(&plan, 0, sizeof(plan));
     plan.dim = c->g.dim;
     for (int d = 0; d < 3; ++d) plan.dx[d] = c->g.dx[d];
     plan.cfl = c->params.cfl;
+    plan.force_dt = c->params.force_dt;
     if (ns + na > 24) return 1;
     for (int s = 0; s < ns; ++s) {
         if (state_viscous(c, s)) return 1;
@@ -1297,28 +1302,23 @@ int cmfp_advance_steps(cmfp_context* c, double, double dt0, int nsteps, double* 
             plan.word[n] = ns + a;
             plan.cst[n] = action_dt_from(c, a, std::numeric_limits<double>::max());
         }
-    double* d_dt = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_dt, sizeof(double) * (size_t)(nsteps + 1)));
     double* d_log = d_dt + 1;
-    auto cleanup = [&]() {
-        c->g.dtp = nullptr;
-        (void)hipFree(d_dt);
-    };
-    hipError_t e = hipMemcpyAsync(d_dt, &dt0, sizeof(double), hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) {
-        cleanup();
-        return fail(c, CMFP_ERR_HIP, hipGetErrorString(e));
-    }
+    // whatever happens below, no later call may find the kernels' dt still redirected to d_dt
+    struct DtpGuard {
+        cmfp_context* c;
+        ~DtpGuard() { c->g.dtp = nullptr; }
+    } guard{c};
+    HIPCHK(c, hipMemcpyAsync(d_dt, &dt0, sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->g.dtp = d_dt;
+    int done = 0, rc = CMFP_OK;
     for (int i = 0; i < nsteps; ++i) {
         std::fill(c->red_valid.begin(), c->red_valid.end(), 0);
         r = advance_strang_fused(c, 1.0);  // dt arguments become factors of *dtp
         if (r <= 0) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            cleanup();
-            if (r < 0) return r;
-            if (i == 0) return 1;  // configuration outside the fused kernels: nothing was advanced
-            return fail(c, CMFP_ERR_INVALID, "fused path became unavailable between steps");
+            if (r == 0 && i == 0) rc = 1;  // configuration outside the fused kernels: nothing was advanced
+            else if (r == 0) rc = fail(c, CMFP_ERR_INVALID, "fused path became unavailable between steps");
+            else rc = r;
+            break;
         }
         c->last_fused = r;
         for (int s = 0; s < ns; ++s)
@@ -1332,19 +1332,48 @@ int cmfp_advance_steps(cmfp_context* c, double, double dt0, int nsteps, double* 
                 c->red_valid[ns + a] = 1;
             }
         c->L->new_dt(plan, c->d_red, d_dt, d_log, i, c->stream);
+        done = i + 1;
         if (split_any && c->dt_reduce(c->dt_reduce_user, c, d_dt)) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            cleanup();
-            return fail(c, CMFP_ERR_INVALID, "dt reduce callback failed");
+            rc = fail(c, CMFP_ERR_INVALID, "dt reduce callback failed");
+            break;
         }
     }
     c->g.dtp = nullptr;
-    e = hipMemcpyAsync(dts, d_log, sizeof(double) * (size_t)nsteps, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dt_next, d_dt, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    // The dt of every completed step and the next one are handed back also when the batch stopped early
+    // (dts[done..nsteps) = 0), so that the caller still knows the time the states have reached.
+    for (int i = done; i < nsteps; ++i) dts[i] = 0.0;
+    *dt_next = dt0;
+    hipError_t e = hipSuccess;
+    if (done) e = hipMemcpyAsync(dts, d_log, sizeof(double) * (size_t)done, hipMemcpyDeviceToHost, c->stream);
+    if (done && e == hipSuccess) e = hipMemcpyAsync(dt_next, d_dt, sizeof(double), hipMemcpyDeviceToHost, c->stream);
     r = sync_and_check(c);
-    (void)hipFree(d_dt);
+    if (rc) return rc;
     if (e != hipSuccess) return fail(c, CMFP_ERR_HIP, hipGetErrorString(e));
     return r;
+}
+
+static int advance_steps_applicable(cmfp_context* c, int nsteps, double* dts, double* dt_next) {
+    if (nsteps < 1 || !dts || !dt_next) return fail(c, CMFP_ERR_INVALID, "bad arguments");
+    if (!c->fused) return 1;
+    bool split_any = false;
+    for (int d = 0; d < c->g.dim; ++d) split_any = split_any || c->split[d];
+    if (split_any && !c->dt_reduce) return 1;  // the cross-rank dt minimum needs a callback, else the per-step API
+    return CMFP_OK;
+}
+
+int cmfp_advance_steps(cmfp_context* c, double, double dt0, int nsteps, double* dts, double* dt_next) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if ((r = advance_steps_applicable(c, nsteps, dts, dt_next))) return r;
+    if (c->d_dtcap < nsteps + 1) {  // dt word + log, kept with the context and grown on demand
+        if (c->d_dtbuf) (void)hipFree(c->d_dtbuf);
+        c->d_dtbuf = nullptr;
+        c->d_dtcap = 0;
+        const int cap = std::max(nsteps + 1, 257);
+        HIPCHK(c, hipMalloc((void**)&c->d_dtbuf, sizeof(double) * (size_t)cap));
+        c->d_dtcap = cap;
+    }
+    return advance_steps_on(c, dt0, nsteps, dts, dt_next, c->d_dtbuf);
 }
 
 int cmfp_state_set_face_values(cmfp_context* c, int s, int dim, int side, int prim, const double* cell_values,

@@ -1367,6 +1367,7 @@ __global__ void k_new_dt(DtPlan p, const unsigned long long* __restrict__ red, d
         est = std_min(est, d);
     }
     est *= p.cfl;
+    if (p.force_dt > 0.0) est = p.force_dt;  // MFP_timestep.cpp:8
     const double old = dt[0];
     log[idx] = old;
     dt[0] = std_min(est, 1.1 * old);

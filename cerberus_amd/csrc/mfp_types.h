@@ -140,6 +140,7 @@ struct DtPlan {
     int dim;
     double dx[3];
     double cfl;
+    double force_dt;  // > 0: MFP::estTimeStep returns it before anything else (MFP_timestep.cpp:8)
 };
 
 // Host-side launchers of one floating-point mode (namespace strict / fast).

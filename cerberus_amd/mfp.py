@@ -46,6 +46,7 @@ class MFP:
         self.p = problem if isinstance(problem, Problem) else Problem(problem)
         p = self.p
         self.rank, self.world, self.pg = rank, world, pg
+        self._stream = int(stream or 0)
         self.grid = block_grid(p.dim, world)
         self.coords = rank_coords(rank, self.grid)
         self.block_n, self.block_lo = [1, 1, 1], [0, 0, 0]
@@ -281,7 +282,8 @@ class MFP:
             dev = self._pack_device()
             dbuf = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(4)]
             if self._exchange_device is not None and torch.device(self._exchange_device) != dev:
-                # host-staged transport (gloo): pinned mirrors of the four device buffers
+                # host-staged transport (gloo): host mirrors of the four device buffers (pageable: the copies
+                # to and from them are synchronous, which the exchange relies on)
                 hbuf = [torch.empty(n, dtype=torch.float64, device=self._exchange_device) for _ in range(4)]
             else:
                 hbuf = dbuf
@@ -292,29 +294,44 @@ class MFP:
         import torch
         return torch.device("cuda", torch.cuda.current_device())
 
+    def _stream_ctx(self):
+        """The library enqueues packs, unpacks and cmfp_copy_async on the context's stream; the torch copies
+        and collectives of the hooks below are ordered against torch's *current* stream.  With a context on
+        a non-default stream that stream is made current for the duration of the hook, so that pack -> send
+        and recv -> unpack stay in one stream order ('streams')."""
+        import contextlib
+        if not getattr(self, "_stream", 0):
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(torch.cuda.ExternalStream(self._stream))
+
     def _dt_reduce(self, user, ctx, ptr):
         """cmfp_dt_reduce_fn: all-reduce(MIN) of the device-resident dt (ReduceRealMin, MFP_timestep.cpp:18),
         enqueued in stream order: no host synchronisation with RCCL."""
         try:
             import torch
             import torch.distributed as dist
-            if self._dt_buf is None:
-                self._dt_buf = torch.empty(1, dtype=torch.float64, device=self._pack_device())
-            buf = self._dt_buf
-            self._chk(self.L.cmfp_copy_async(self.h, C.c_void_p(buf.data_ptr()), C.c_void_p(ptr), 8))
-            if self._exchange_device is not None and torch.device(self._exchange_device) != buf.device:
-                h = buf.to(self._exchange_device)     # host-staged transport (gloo)
-                dist.all_reduce(h, op=dist.ReduceOp.MIN, group=self.pg)
-                buf.copy_(h)
-            else:
-                dist.all_reduce(buf, op=dist.ReduceOp.MIN, group=self.pg)
-            self._chk(self.L.cmfp_copy_async(self.h, C.c_void_p(ptr), C.c_void_p(buf.data_ptr()), 8))
-            return 0
+            with self._stream_ctx():
+                return self._dt_reduce_body(torch, dist, ptr)
         except Exception as e:  # never let an exception cross the C boundary
             import traceback
             traceback.print_exc()
             self._exchange_error = e
             return 1
+
+    def _dt_reduce_body(self, torch, dist, ptr):
+        if self._dt_buf is None:
+            self._dt_buf = torch.empty(1, dtype=torch.float64, device=self._pack_device())
+        buf = self._dt_buf
+        self._chk(self.L.cmfp_copy_async(self.h, C.c_void_p(buf.data_ptr()), C.c_void_p(ptr), 8))
+        if self._exchange_device is not None and torch.device(self._exchange_device) != buf.device:
+            h = buf.to(self._exchange_device)     # host-staged transport (gloo)
+            dist.all_reduce(h, op=dist.ReduceOp.MIN, group=self.pg)
+            buf.copy_(h)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.MIN, group=self.pg)
+        self._chk(self.L.cmfp_copy_async(self.h, C.c_void_p(ptr), C.c_void_p(buf.data_ptr()), 8))
+        return 0
 
     def _exchange(self, user, ctx, s, d):
         """cmfp_exchange_fn: pack both faces, swap with the neighbours, unpack.
@@ -322,49 +339,53 @@ class MFP:
         faces of every state travel back to back in one message per neighbour."""
         try:
             import torch.distributed as dist
-            states = list(range(self.n_states)) if s < 0 else [s]
-            counts = [self._halo_count(q, d) for q in states]
-            offs = [sum(counts[:k]) for k in range(len(counts))]
-            dbuf, xbuf = self._buffers(s, d, sum(counts))
-            staged = xbuf is not dbuf
-            nb_lo, nb_hi = self.neighbour(d, 0), self.neighbour(d, 1)
-            for q, off, n in zip(states, offs, counts):
-                if nb_lo is not None:
-                    self._halo_pack(q, d, 0, dbuf[0][off:off + n])
-                if nb_hi is not None:
-                    self._halo_pack(q, d, 1, dbuf[1][off:off + n])
-            if staged:
-                for k in (0, 1):
-                    xbuf[k].copy_(dbuf[k])
-            ops = []
-            if nb_lo is not None and nb_lo == nb_hi:
-                # two ranks along a periodic dimension: both messages go to the same peer and are
-                # matched in order; the peer's low face (its first send) is my high ghost
-                ops = [dist.P2POp(dist.isend, xbuf[0], nb_lo, group=self.pg),
-                       dist.P2POp(dist.isend, xbuf[1], nb_hi, group=self.pg),
-                       dist.P2POp(dist.irecv, xbuf[3], nb_hi, group=self.pg),
-                       dist.P2POp(dist.irecv, xbuf[2], nb_lo, group=self.pg)]
-            else:
-                if nb_lo is not None:
-                    ops.append(dist.P2POp(dist.isend, xbuf[0], nb_lo, group=self.pg))
-                    ops.append(dist.P2POp(dist.irecv, xbuf[2], nb_lo, group=self.pg))
-                if nb_hi is not None:
-                    ops.append(dist.P2POp(dist.isend, xbuf[1], nb_hi, group=self.pg))
-                    ops.append(dist.P2POp(dist.irecv, xbuf[3], nb_hi, group=self.pg))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            if staged:
-                for k in (2, 3):
-                    dbuf[k].copy_(xbuf[k])
-            for q, off, n in zip(states, offs, counts):
-                if nb_lo is not None:
-                    self._halo_unpack(q, d, 0, dbuf[2][off:off + n])
-                if nb_hi is not None:
-                    self._halo_unpack(q, d, 1, dbuf[3][off:off + n])
-            return 0
+            with self._stream_ctx():
+                return self._exchange_body(dist, s, d)
         except Exception as e:  # never let an exception cross the C boundary
             import traceback
             traceback.print_exc()
             self._exchange_error = e
             return 1
+
+    def _exchange_body(self, dist, s, d):
+        states = list(range(self.n_states)) if s < 0 else [s]
+        counts = [self._halo_count(q, d) for q in states]
+        offs = [sum(counts[:k]) for k in range(len(counts))]
+        dbuf, xbuf = self._buffers(s, d, sum(counts))
+        staged = xbuf is not dbuf
+        nb_lo, nb_hi = self.neighbour(d, 0), self.neighbour(d, 1)
+        for q, off, n in zip(states, offs, counts):
+            if nb_lo is not None:
+                self._halo_pack(q, d, 0, dbuf[0][off:off + n])
+            if nb_hi is not None:
+                self._halo_pack(q, d, 1, dbuf[1][off:off + n])
+        if staged:
+            for k in (0, 1):
+                xbuf[k].copy_(dbuf[k])
+        ops = []
+        if nb_lo is not None and nb_lo == nb_hi:
+            # two ranks along a periodic dimension: both messages go to the same peer and are
+            # matched in order; the peer's low face (its first send) is my high ghost
+            ops = [dist.P2POp(dist.isend, xbuf[0], nb_lo, group=self.pg),
+                   dist.P2POp(dist.isend, xbuf[1], nb_hi, group=self.pg),
+                   dist.P2POp(dist.irecv, xbuf[3], nb_hi, group=self.pg),
+                   dist.P2POp(dist.irecv, xbuf[2], nb_lo, group=self.pg)]
+        else:
+            if nb_lo is not None:
+                ops.append(dist.P2POp(dist.isend, xbuf[0], nb_lo, group=self.pg))
+                ops.append(dist.P2POp(dist.irecv, xbuf[2], nb_lo, group=self.pg))
+            if nb_hi is not None:
+                ops.append(dist.P2POp(dist.isend, xbuf[1], nb_hi, group=self.pg))
+                ops.append(dist.P2POp(dist.irecv, xbuf[3], nb_hi, group=self.pg))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if staged:
+            for k in (2, 3):
+                dbuf[k].copy_(xbuf[k])
+        for q, off, n in zip(states, offs, counts):
+            if nb_lo is not None:
+                self._halo_unpack(q, d, 0, dbuf[2][off:off + n])
+            if nb_hi is not None:
+                self._halo_unpack(q, d, 1, dbuf[3][off:off + n])
+        return 0

@@ -118,6 +118,8 @@ typedef struct {
     int time_integrator; /* cmfp_time_integrator */
     int fp_mode;         /* cmfp_fp_mode          */
     double n0;           /* MFP::n0 = n_ref x_ref^3 (MFP_config.cpp:390-392); collisions only */
+    double force_dt;     /* Lua 'force_dt' (default.lua, MFP_config.cpp): > 0 makes MFP::estTimeStep return it  */
+                         /* before anything else (MFP_timestep.cpp:8); <= 0: the CFL estimate                   */
 } cmfp_params;
 
 /* One Eulerian state, in the reference's sorted-name order
@@ -259,7 +261,10 @@ int cmfp_advance(cmfp_context* ctx, double time, double dt);
  * step's dt; dts[0..nsteps): the dt each step used; dt_next: the one computeNewDt leaves for the
  * next step.  Same arithmetic as cmfp_est_time_step / cmfp_compute_new_dt: STRICT results are
  * bit-identical to the per-step calls.  Returns 1 without advancing where it does not apply (stage-by-stage
- * path, viscous states, a block split between ranks: the cross-rank dt reduction is the caller's). */
+ * path, viscous states, a block split between ranks: the cross-rank dt reduction is the caller's).  If the
+ * batch stops early with an error, dts[0..k) holds the dt of the k steps that were completed, dts[k..nsteps)
+ * is 0 and dt_next the dt the next step would use, so the caller still knows the time the states reached.
+ * params.force_dt > 0 (MFP_timestep.cpp:8) keeps every dt at that value. */
 int cmfp_advance_steps(cmfp_context* ctx, double time, double dt0, int nsteps, double* dts, double* dt_next);
 /* Uses hand-fused kernels inside cmfp_advance where available (default 1: the
  * LDS-tiled kernel for 2-D blocks, the tile-free gather kernels for 1-D and 3-D);

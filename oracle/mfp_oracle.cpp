@@ -2030,6 +2030,7 @@ struct Sim {
 
     // MFP::estTimeStep  MFP_timestep.cpp:4-21
     Real est_time_step() const {
+        if (P.force_dt > 0.0) { return P.force_dt; }  // :8
         Real estdt = std::numeric_limits<Real>::max();
         for (size_t s = 0; s < states.size(); ++s) estdt = std::min(estdt, state_allowed_dt((int)s));
         for (size_t a = 0; a < actions.size(); ++a) estdt = std::min(estdt, action_allowed_dt((int)a));

@@ -262,6 +262,31 @@ def test_collisions_relaxation_parity(oracle, neutral):
         m.close()
 
 
+def test_force_dt(oracle):
+    """force_dt > 0 is what MFP::estTimeStep returns (MFP_timestep.cpp:8): per-step driver, device-resident
+    dt loop and oracle all step with exactly force_dt; states bit-identical (hard-sphere branch)."""
+    P = config.Problem(problems.collisions_relaxation(8, True), fp_mode=abi.FP_STRICT)
+    ref = oracle.OracleSim(P)
+    assert ref.run(6) == [1e-4] * 6
+    m = _gpu(P)
+    assert m.est_time_step() == 1e-4
+    assert m.run(6) == [1e-4] * 6
+    for s in range(2):
+        assert np.array_equal(m.download(s), ref.get_state(s))
+    m.close()
+    # Strang two-fluid problem on the fused kernels: the device-side computeNewDt keeps dt = force_dt
+    cfg = problems.orszag_tang_two_fluid_2d(32)
+    cfg["force_dt"] = 2.5e-4
+    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    ref = oracle.OracleSim(P)
+    assert ref.run(5) == [2.5e-4] * 5
+    m = _gpu(P, fused=True)
+    assert m.run(5) == [2.5e-4] * 5 and m.dt == 2.5e-4 and m.last_advance_fused()
+    for s in range(3):
+        assert np.array_equal(m.download(s), ref.get_state(s))
+    m.close()
+
+
 def test_collisions_with_plasma5_fused(oracle):
     """two-fluid Orszag-Tang with ion-electron collisions beside plasma5: the fused Strang step
     evaluates both sources in one kernel; the staged path runs them as two actions."""

@@ -225,6 +225,20 @@ def test_collisions_conserve_and_equilibrate(oracle, neutral):
     assert Ta.min() > uT(U0[0])[1].max()          # the beam's drift energy became heat
 
 
+def test_force_dt_overrides_the_cfl_estimate(oracle):
+    """MFP::estTimeStep returns force_dt before anything else (MFP_timestep.cpp:8): the shipped
+    collisions problem (force_dt = 1e-4) steps with exactly that value, growth cap included."""
+    from cerberus_amd import config, problems
+    P = config.Problem(problems.collisions_relaxation(4, False))
+    assert P.force_dt == 1e-4
+    sim = oracle.OracleSim(P)
+    assert sim.est_time_step() == 1e-4
+    assert sim.run(5) == [1e-4] * 5
+    cfg = problems.collisions_relaxation(4, False)
+    cfg["force_dt"] = 0.0
+    assert oracle.OracleSim(config.Problem(cfg)).est_time_step() != 1e-4
+
+
 # ---- passive scalars (tracers) ------------------------------------------------------------
 def _kh_tracers(flux="HLLC", n=32):
     cfg = problems.kelvin_helmholtz_2d(n, flux=flux, recon="vanLeer")
