@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -89,6 +90,7 @@ struct cmfp_context {
     int* d_err = nullptr;
     double* d_dtbuf = nullptr;  // cmfp_advance_steps: device-resident dt + dt log
     int d_dtcap = 0;
+    bool no_alloc = false;  // inside cmfp_advance_steps_static: anything that would allocate fails instead
     unsigned long long* d_red = nullptr;  // one reduction word per state + per action
     double* d_part = nullptr;             // CMFP_RED_BLOCKS block partials per word
     std::vector<char> red_valid;          // word already holds the reduction of the current new-time data
@@ -127,8 +129,8 @@ struct ProfScope {
         if (!c->ev_pool.empty()) {
             e = c->ev_pool.back();
             c->ev_pool.pop_back();
-        } else if (hipEventCreate(&e) != hipSuccess) {
-            e = nullptr;
+        } else if (c->no_alloc || hipEventCreate(&e) != hipSuccess) {
+            e = nullptr;  // no timing for this launch
         }
         return e;
     }
@@ -149,6 +151,9 @@ struct ProfScope {
 
 int dalloc(cmfp_context* c, double** p, long n) {
     if (*p) return CMFP_OK;
+    if (c->no_alloc)
+        return fail(c, CMFP_ERR_INVALID, "cmfp_advance_steps_static: the fused step still has scratch to allocate for this kernel "
+                                         "selection; run one cmfp_advance first");
     HIPCHK(c, hipMalloc((void**)p, sizeof(double) * (size_t)n));
     c->allocs.push_back(*p);
     return CMFP_OK;
@@ -582,7 +587,7 @@ int advance_strang(cmfp_context* c, double dt) {
 // place, one fused CTU kernel per state writing new + dU into the ping-pong
 // partner.  Returns 1 if it ran, 0 if the configuration is outside what the
 // fused kernels cover (caller then takes the staged path), <0 on error.
-int advance_strang_fused(cmfp_context* c, double dt) {
+int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) {
     if (c->params.time_integrator != CMFP_TI_STRANG) return 0;
     int n_src = 0, src = -1, coll = -1;
     std::vector<int> seen(c->states.size(), 0);
@@ -662,11 +667,18 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     bool src_split = false;
     IBox src_inner;
     if ((overlap || (src >= 0 && split_any && c->overlap != 0)) && !c->stream2) {
+        if (c->no_alloc)
+            return fail(c, CMFP_ERR_INVALID, "cmfp_advance_steps_static: the overlap stream does not exist yet; run one cmfp_advance first");
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_int, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_hyd, hipEventDisableTiming));
     }
+    for (int q : list) {  // ping-pong partners of the flux kernels
+        int r;
+        if ((r = dalloc(c, &c->states[q].alt, c->states[q].sp.nc * c->g.sc))) return r;
+    }
+    if (reserve_only) return 1;  // cmfp_create: everything this kernel selection allocates now exists
     if (src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
         if (coll >= 0) a.coll = coll_args(c, c->actions[coll]);
@@ -744,8 +756,6 @@ int advance_strang_fused(cmfp_context* c, double dt) {
     std::vector<unsigned long long*> slots(list.size(), nullptr);
     for (size_t q = 0; q < list.size(); ++q) {
         StateRT& s = c->states[list[q]];
-        int r;
-        if ((r = dalloc(c, &s.alt, s.sp.nc * c->g.sc))) return r;
         // a hydro state no source action touches afterwards: the CTU kernel is the last writer of
         // the step and also leaves the CFL reduction of what it wrote
         bool reduce = s.sp.kind == CMFP_STATE_HYDRO;
@@ -860,6 +870,29 @@ int advance_strang_fused(cmfp_context* c, double dt) {
         if (a.limits_dt) c->red_valid[c->states.size() + src] = 1;
     }
     return any_gather ? 2 : 1;
+}
+
+// ---- cmfp_advance_steps_static: the device words of cmfp_advance_steps (time step + dt log) in the library
+// image instead of an allocation.  One copy of the array per GPU, each at its own address: the name
+// `scratch` is a host-side stand-in (never passed to a kernel or a memcpy); the address on a device is
+// resolved once with that device current and kept in g_scratch_ptr.
+static __device__ __align__(256) double scratch[CMFP_STATIC_MAX_STEPS + 1];
+constexpr int kMaxDevices = 64;
+double* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+// device address of `scratch` on the context's device (which the caller has made current)
+int static_scratch(cmfp_context* c, double** out) {
+    if (c->device < 0 || c->device >= kMaxDevices) return fail(c, CMFP_ERR_INVALID, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[c->device]) {
+        double* p = nullptr;
+        HIPCHK(c, hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(c, CMFP_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+        g_scratch_ptr[c->device] = p;
+    }
+    *out = g_scratch_ptr[c->device];
+    return CMFP_OK;
 }
 
 int check_ctx(cmfp_context* c) {
@@ -1008,6 +1041,16 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     HIPCHK(c, hipMalloc((void**)&c->d_red, sizeof(unsigned long long) * (2 * n_states + n_actions + 1)));
     HIPCHK(c, hipMalloc((void**)&c->d_part, sizeof(double) * (size_t)(2 * n_states + n_actions + 1) * CMFP_RED_BLOCKS));
     c->red_valid.assign(2 * n_states + n_actions + 1, 0);
+    {
+        // what the fused Strang step of the default kernel selection allocates (ping-pong partners, flux
+        // scratch) is reserved now, so that stepping never allocates: cmfp_advance_steps_static relies on it
+        const int r = advance_strang_fused(c, 0.0, true);
+        if (r < 0) return r;
+        // this device's address of the static scratch array, resolved once per device here (set-up)
+        double* p = nullptr;
+        int r2;
+        if ((r2 = static_scratch(c, &p))) return r2;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CMFP_OK;
 }
@@ -1374,6 +1417,25 @@ int cmfp_advance_steps(cmfp_context* c, double, double dt0, int nsteps, double* 
         c->d_dtcap = cap;
     }
     return advance_steps_on(c, dt0, nsteps, dts, dt_next, c->d_dtbuf);
+}
+
+// The same with the dt word and the dt log in the library's file-scope device array: no hipMalloc / hipFree,
+// no stream or event creation (include/cerberus_mfp.h).
+int cmfp_advance_steps_static(cmfp_context* c, double, double dt0, int nsteps, double* dts, double* dt_next) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if ((r = advance_steps_applicable(c, nsteps, dts, dt_next))) return r;
+    if (nsteps > CMFP_STATIC_MAX_STEPS)
+        return fail(c, CMFP_ERR_INVALID, "cmfp_advance_steps_static: nsteps exceeds CMFP_STATIC_MAX_STEPS (" +
+                                             std::to_string(CMFP_STATIC_MAX_STEPS) + "); split the batch");
+    double* d_dt = nullptr;
+    if ((r = static_scratch(c, &d_dt))) return r;  // resolved by cmfp_create on this device: a table lookup here
+    struct Guard {
+        cmfp_context* c;
+        ~Guard() { c->no_alloc = false; }
+    } guard{c};
+    c->no_alloc = true;
+    return advance_steps_on(c, dt0, nsteps, dts, dt_next, d_dt);
 }
 
 int cmfp_state_set_face_values(cmfp_context* c, int s, int dim, int side, int prim, const double* cell_values,

@@ -39,6 +39,7 @@ SYMBOLS = [
     ("cmfp_compute_new_dt", C.c_double, [C.c_double, C.c_double]),
     ("cmfp_advance", C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     ("cmfp_advance_steps", C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, dp, dp]),
+    ("cmfp_advance_steps_static", C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, dp, dp]),
     ("cmfp_set_fused", C.c_int, [C.c_void_p, C.c_int]),
     ("cmfp_last_advance_fused", C.c_int, [C.c_void_p]),
     ("cmfp_profile_enable", C.c_int, [C.c_void_p, C.c_int]),

@@ -266,6 +266,20 @@ int cmfp_advance(cmfp_context* ctx, double time, double dt);
  * is 0 and dt_next the dt the next step would use, so the caller still knows the time the states reached.
  * params.force_dt > 0 (MFP_timestep.cpp:8) keeps every dt at that value. */
 int cmfp_advance_steps(cmfp_context* ctx, double time, double dt0, int nsteps, double* dts, double* dt_next);
+/* cmfp_advance_steps for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same
+ * arguments, results and return codes as cmfp_advance_steps, but the device-resident time step, the dt
+ * log of the batch and nothing else live in a file-scope `static __device__` array of the library
+ * (one copy per GPU, CMFP_STATIC_MAX_STEPS + 1 doubles, held until the process ends) instead of a buffer
+ * the call allocates, and the call makes no hipMalloc / hipFree / stream or event creation of any kind:
+ * nsteps > CMFP_STATIC_MAX_STEPS is refused with CMFP_ERR_INVALID, and so is a context whose fused step
+ * would still have to allocate its ping-pong / flux scratch (cmfp_create reserves it for the default
+ * kernel selection; after cmfp_set_fused(2 or 3) or on a block split between ranks run one cmfp_advance
+ * first).  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two
+ * contexts on different streams) race; calls in sequence are independent (the call rewrites every word
+ * it reads). */
+#define CMFP_STATIC_MAX_STEPS 4096
+int cmfp_advance_steps_static(cmfp_context* ctx, double time, double dt0, int nsteps, double* dts, double* dt_next);
 /* Uses hand-fused kernels inside cmfp_advance where available (default 1: the
  * LDS-tiled kernel for 2-D blocks, the tile-free gather kernels for 1-D and 3-D);
  * 2 forces the gather kernels in any dimensionality; 0 forces the stage-by-stage
