@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--tiled-hydro", action="store_true", help="diagnostic: LDS-tiled hydro CTU kernel instead of the wave-marching one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (profiling runs): no STRICT / other-workload legs")
     ap.add_argument("--rehearse", action="store_true",
                     help="diagnostic: run the N-rank path on ONE GPU (all ranks on cuda:0, gloo with host-staged halos); not a measurement")
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2],
