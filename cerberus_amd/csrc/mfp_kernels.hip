@@ -752,6 +752,18 @@ __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs 
             st_plane(a.f_U + F_DZ * g.sc, c, 0.5 * f0[F_DZ] + 0.5 * (f1[F_DZ] + fdU[2]));
             st_plane(a.f_U + F_PHI * g.sc, c, 0.5 * f0[F_PHI] + 0.5 * (f1[F_PHI] + fdU[3]));
             st_plane(a.f_U + F_PSI * g.sc, c, 0.5 * f0[F_PSI] + 0.5 * (f1[F_PSI] + fdU[4]));
+#ifndef CMFP_FASTMATH
+            // The components no source term touches also go through the reference's 0.5 x + 0.5 (x + 0 + 0)
+            // (plasma5 marks the whole field state as changed, MFP_plasma5.cpp:96).  That is x for every
+            // normal number; for a subnormal x with an odd last bit 0.5 x rounds, and the sum is x +- 1 ulp
+            // (seen at the foot of a wave front running into a field that is exactly zero).  STRICT follows the
+            // reference there too; the store happens only for such values.
+#pragma unroll
+            for (int n : {F_BX, F_BY, F_BZ, F_MU, F_EP}) {
+                const double y = 0.5 * f0[n] + 0.5 * f0[n];
+                if (y != f0[n]) st_plane(a.f_U + n * g.sc, c, y);
+            }
+#endif
         }
     }
     if (REDUCE) {

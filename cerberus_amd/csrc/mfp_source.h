@@ -156,6 +156,12 @@ CMFP_DEV void source_epilogue_cell(const Geo& g, const SourceEpi& epi, double dt
         Unew[F_DZ] = fnew[2];
         Unew[F_PHI] = fnew[3];
         Unew[F_PSI] = fnew[4];
+#ifndef CMFP_FASTMATH
+        // components no source term touches: the reference's 0.5 x + 0.5 x, which is x except for subnormal
+        // values with an odd last bit (see k_source_rk2)
+#pragma unroll
+        for (int n : {F_BX, F_BY, F_BZ, F_MU, F_EP}) Unew[n] = 0.5 * Unew[n] + 0.5 * Unew[n];
+#endif
     }
 }
 

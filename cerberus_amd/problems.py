@@ -306,6 +306,58 @@ def richtmyer_meshkov_3d(n=512, ny=None, nz=None):
     }
 
 
+def cavity_mode_2d(n=32, m=1, l=1, Lx=1.0, Ly=1.0, recon="O6"):
+    """A TM_ml eigenmode of a rectangular cavity with perfectly conducting walls, with the option set of the
+    reference's field-only example Exec/testing/Waveguide/Waveguide.inputs (lightspeed = 1, cfl = 0.5, `euler`,
+    field O6 + RankineHugoniot, CTU with corner transport).  That example builds its conductor out of embedded
+    boundaries (out of scope); on the uniform grid the conducting wall is the `asymmetry` field boundary
+    (MFP_bc.cpp:99-109: tangential D and normal B odd, normal D and tangential B even).  Analytic solution:
+    D_z = sin(kx x) sin(ky y) cos(w t), B_x = -(c ky / w) sin(kx x) cos(ky y) sin(w t),
+    B_y = (c kx / w) cos(kx x) sin(ky y) sin(w t), w = c sqrt(kx^2 + ky^2), kx = m pi / Lx, ky = l pi / Ly."""
+    kx, ky = m * math.pi / Lx, l * math.pi / Ly
+    wall = {k: {"fill_D_bc": "asymmetry", "fill_B_bc": "asymmetry", "fill_phi_bc": "symmetry", "fill_psi_bc": "symmetry",
+                "fill_mu_bc": "symmetry", "fill_ep_bc": "symmetry"} for k in ("lo", "hi")}
+    return {
+        "dim": 2, "n_cell": [n, max(2, int(round(n * Ly / Lx)))], "prob_lo": [0.0, 0.0], "prob_hi": [Lx, Ly],
+        "is_periodic": [0, 0], "cfl": 0.5, "time_integration_scheme": "euler", "lightspeed": 1.0,
+        "states": {"field": {"type": "field", "reconstruction": recon, "flux": "RankineHugoniot",
+                             "value": {"z_D": lambda d: np.sin(kx * d["x"]) * np.sin(ky * d["y"])},
+                             "bc": {"x": wall, "y": wall}}},
+        "actions": {"fluxes": {"type": "CTU", "corner_transport": True, "states": ["field"]}},
+        "_mode": {"kx": kx, "ky": ky, "omega": math.sqrt(kx * kx + ky * ky)},
+    }
+
+
+def uniform_plasma_2d(n=8, source="plasma5", u0=1e-3, B0=0.0, mass_ratio=25.0, lightspeed=20.0, skin_depth=0.2, beta=1.0):
+    """A uniform, periodic two-fluid plasma: the flux update is exactly zero, so only the source action acts.
+    plasma5 with a small electron drift u0 along x (no magnetic field): Langmuir oscillation of the current at
+    w_p^2 = sum_s rho_s (q_s / m_s)^2 / Debye^2.  Lorentz with a uniform B_z = B0: each species gyrates at
+    w_c = |q_s / m_s| B0 / Larmor.  Both frequencies are the ones the reference's own dt limit is built from
+    (MFP_plasma5.cpp:549-555) and follow from its source terms (:123-129, 213-235)."""
+    gam = 5 / 3
+    hydro = lambda m, q, u: {
+        "type": "hydro", "gas": {"type": "thermally_perfect", "mass": m, "charge": q, "gamma": gam},
+        "reconstruction": "minmod", "flux": "HLLC",
+        "value": {"rho": 1.0 * m, "x_vel": u, "y_vel": 0.0, "z_vel": 0.0, "p": 0.5}}
+    src = {"type": source, "states": ["ion", "electron", "field"]}
+    if source == "plasma5":
+        src["solver"] = "explicit"
+    return {
+        "dim": 2, "n_cell": [n, n], "prob_lo": [0.0, 0.0], "prob_hi": [1.0, 1.0], "is_periodic": [1, 1],
+        "cfl": 0.3, "time_integration_scheme": "strang", "lightspeed": lightspeed, "skin_depth": skin_depth, "beta": beta,
+        "states": {
+            "ion": hydro(1.0, 1.0, u0 if source == "Lorentz" else 0.0),
+            "electron": hydro(1.0 / mass_ratio, -1.0, u0),
+            "field": {"type": "field", "reconstruction": "O6", "flux": "RankineHugoniot", "value": {"z_B": B0}},
+        },
+        "actions": {
+            "em_fluxes": {"type": "CTU", "corner_transport": True, "states": ["field"]},
+            "hydro_fluxes": {"type": "CTU", "corner_transport": True, "states": ["ion", "electron"]},
+            "plasma": src,
+        },
+    }
+
+
 WORKLOADS = {
     "brio_wu_1d": brio_wu_two_fluid_1d,
     "kh_2d": kelvin_helmholtz_2d,

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from cerberus_amd import abi, config, problems
-from helpers import rel_linf, small_cases
+from helpers import rel_linf, small_cases, survey_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -86,8 +86,37 @@ def test_device_resident_dt_equals_per_step_calls(case):
     b.close()
 
 
+@pytest.mark.parametrize("case", range(5))
+def test_survey_size_parity(oracle, case):
+    """The parity runs at the sizes SURVEY.md section 8(d) names (2048 cells x 100 steps; 256^2 x 20; 256 x 128 x 20;
+    64^3 x 10) on the default (fused) kernels: STRICT bit-identical states and dt sequence, FAST - the arithmetic
+    bench.py measures - within the north-star bound of 1e-12 relative L-infinity after all N steps."""
+    name, cfg, steps = survey_cases()[case]
+    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    ref = oracle.OracleSim(P, max_grid_size=32)
+    dts_ref = ref.run(steps)
+    refs = [ref.get_state(s) for s in range(len(P.state_names))]
+    del ref
+    m = _gpu(P)
+    dts = m.run(steps)
+    assert m.last_advance_path() != 0
+    assert dts == dts_ref, name
+    for s in range(m.n_states):
+        assert np.array_equal(m.download(s), refs[s]), (name, P.state_names[s], rel_linf(m.download(s), refs[s]))
+    m.close()
+    m = _gpu(config.Problem(cfg, fp_mode=abi.FP_FAST))
+    dts = m.run(steps)
+    np.testing.assert_allclose(dts, dts_ref, rtol=1e-12)
+    for s in range(m.n_states):
+        assert rel_linf(m.download(s), refs[s]) <= TOL_FAST, (name, P.state_names[s], rel_linf(m.download(s), refs[s]))
+    m.close()
+
+
+ALL_GOLDEN = small_cases() + survey_cases()
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,cfg,steps", small_cases(), ids=[c[0] for c in small_cases()])
+@pytest.mark.parametrize("name,cfg,steps", ALL_GOLDEN, ids=[c[0] for c in ALL_GOLDEN])
 def test_strict_gpu_matches_committed_nstep_vectors(name, cfg, steps):
     """STRICT HIP path against the committed N-step vectors (tests/golden/oracle_nstep.json): dt sequence
     and every conserved value bit for bit, without the oracle in the loop"""

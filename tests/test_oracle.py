@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from cerberus_amd import abi, config, problems
-from helpers import rel_linf, small_cases
+from helpers import rel_linf, small_cases, survey_cases
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 KAT = json.load(open(os.path.join(HERE, "golden", "survey_kat.json")))
@@ -312,14 +312,18 @@ def test_inflow_face_imposes_the_profile(oracle):
 
 
 # ---- committed N-step vectors (tests/golden/oracle_nstep.json, tools/make_golden_nstep.py) ----------
-@pytest.mark.parametrize("name,cfg,steps", small_cases(), ids=[c[0] for c in small_cases()])
+ALL_GOLDEN = small_cases() + survey_cases()
+
+
+@pytest.mark.parametrize("name,cfg,steps", ALL_GOLDEN, ids=[c[0] for c in ALL_GOLDEN])
 def test_oracle_reproduces_committed_nstep_vectors(oracle, name, cfg, steps):
     """the restatement's N-step result (dt sequence and every conserved value, bit for bit) is the one
     committed with the repository: orchestration, ghost fill and integrator order cannot drift silently"""
     import hashlib
     G = json.load(open(os.path.join(HERE, "golden", "oracle_nstep.json")))[name]
     P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
-    sim = oracle.OracleSim(P)
+    # the survey-size cases run chopped into 32-cell boxes (as the reference's inputs do; one thread per box)
+    sim = oracle.OracleSim(P, max_grid_size=32 if "@" in name else 0)
     dts = sim.run(G["steps"])
     assert [float(v).hex() for v in dts] == G["dts"]
     for s, sname in enumerate(P.state_names):

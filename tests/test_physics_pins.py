@@ -1,0 +1,182 @@
+"""Analytic physics pins for the half of the path that the reference's only acceptance test
+(Exec/testing/Viscous-Vortex/check.py, hydro only) does not reach: the Maxwell update (FieldRH + O6 +
+`asymmetry` walls + `euler` CTU, the option set of Exec/testing/Waveguide/Waveguide.inputs) against a
+conducting-cavity eigenmode, and the plasma5 / Lorentz scalings (Larmor, Debye, lightspeed:
+MFP_plasma5.cpp:123-129, 213-235) against the plasma and cyclotron frequencies that the reference's own dt
+limit is built from (:549-555).  Tolerances are stated like the reference's check.py (:59-78) states its
+1 %.  Each check runs on the CPU oracle (not-gpu suite) and on the HIP path through the C ABI (gpu suite)."""
+import math
+
+import numpy as np
+import pytest
+
+from cerberus_amd import abi, config, problems
+
+
+class OracleRunner:
+    def __init__(self, oracle, P):
+        self.sim, self.P = oracle.OracleSim(P), P
+
+    def est(self):
+        return self.sim.est_time_step()
+
+    def advance(self, dt):
+        self.sim.advance(dt)
+
+    def state(self, s):
+        return self.sim.get_state(s)
+
+    def close(self):
+        pass
+
+
+class GpuRunner:
+    def __init__(self, P, **kw):
+        from cerberus_amd.mfp import MFP
+        self.m = MFP(P, **kw)
+        self.m.init_data()
+
+    def est(self):
+        return self.m.est_time_step()
+
+    def advance(self, dt):
+        self.m.advance(dt)
+
+    def state(self, s):
+        return self.m.download(s)
+
+    def close(self):
+        self.m.close()
+
+
+# ---- conducting cavity eigenmode -------------------------------------------------------------------------
+CAVITY_TOL = 1e-2     # amplitude of the mode over one full period against cos(w t) / sin(w t): 1 % (of unit amplitude)
+
+
+def check_cavity_mode(make, n, m, l, recon="O6"):
+    cfg = problems.cavity_mode_2d(n, m, l, Lx=1.0, Ly=0.75, recon=recon)
+    mode = cfg["_mode"]
+    P = config.Problem(cfg)
+    run = make(P)
+    dat = P.cell_centres()
+    sz = (np.sin(mode["kx"] * dat["x"]) * np.sin(mode["ky"] * dat["y"]))[0]
+    bx = (np.sin(mode["kx"] * dat["x"]) * np.cos(mode["ky"] * dat["y"]))[0]
+    by = (np.cos(mode["kx"] * dat["x"]) * np.sin(mode["ky"] * dat["y"]))[0]
+    w, T = mode["omega"], 2 * math.pi / mode["omega"]
+    dt = run.est()                         # the reference's constant field dt: cfl * dx / c
+    nsteps = int(math.ceil(T / dt))
+    dt = T / nsteps
+    err, t = 0.0, 0.0
+    proj = lambda a, b: float((a * b).sum() / (b * b).sum())
+    for _ in range(nsteps):
+        run.advance(dt)
+        t += dt
+        U = run.state(0)
+        err = max(err, abs(proj(U[2, 0], sz) - math.cos(w * t)),
+                  abs(proj(U[3, 0], bx) + (mode["ky"] / w) * math.sin(w * t)),
+                  abs(proj(U[4, 0], by) - (mode["kx"] / w) * math.sin(w * t)))
+    U = run.state(0)
+    # after exactly one period the field is the initial one again; the other components stay zero
+    back = np.abs(U[2, 0] - sz).max()
+    other = max(np.abs(U[c]).max() for c in (0, 1, 5, 6, 7))
+    run.close()
+    return err, back, other
+
+
+@pytest.mark.parametrize("n,m,l", [(32, 1, 1), (48, 2, 1)])
+def test_cavity_mode_oracle(oracle, n, m, l):
+    err, back, other = check_cavity_mode(lambda P: OracleRunner(oracle, P), n, m, l)
+    assert err <= CAVITY_TOL and back <= 2 * CAVITY_TOL and other <= 1e-12, (err, back, other)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [abi.FP_STRICT, abi.FP_FAST])
+@pytest.mark.parametrize("n,m,l,recon", [(32, 1, 1, "O6"), (48, 2, 1, "O6"), (64, 1, 2, "O6"), (96, 1, 1, "minmod")])
+def test_cavity_mode_gpu(n, m, l, recon, mode):
+    tol = CAVITY_TOL if recon == "O6" else 5 * CAVITY_TOL    # the limited second-order scheme clips the extrema
+    err, back, other = check_cavity_mode(lambda P: GpuRunner(config.Problem(P.cfg, fp_mode=mode)), n, m, l, recon)
+    assert err <= tol and back <= 2 * tol and other <= 1e-12, (err, back, other)
+
+
+# ---- plasma (Langmuir) and cyclotron oscillations --------------------------------------------------------
+OSC_TOL = 5e-4        # normalised current / momentum over one period against the analytic cosine: 0.05 %
+
+
+def check_langmuir(make, **kw):
+    cfg = problems.uniform_plasma_2d(8, "plasma5", u0=1e-3, **kw)
+    P = config.Problem(cfg)
+    run = make(P)
+    D = P.ref["Debye"]
+    sp = [(i, cfg["states"][nm]["gas"]) for i, nm in enumerate(P.state_names) if cfg["states"][nm]["type"] == "hydro"]
+    r = {i: g["charge"] / g["mass"] for i, g in sp}
+    rho = {i: float(run.state(i)[0].mean()) for i, _ in sp}
+    wp = math.sqrt(sum(rho[i] * r[i] ** 2 for i, _ in sp)) / D
+    J = lambda: sum(r[i] * float(run.state(i)[1].mean()) for i, _ in sp)
+    J0 = J()
+    T = 2 * math.pi / wp
+    nsteps = 400
+    dt, t, err = T / nsteps, 0.0, 0.0
+    assert dt <= run.est() / P.cfl            # below every stability limit of the reference (plasma dt limit = T / 10)
+    for _ in range(nsteps):
+        run.advance(dt)
+        t += dt
+        err = max(err, abs(J() / J0 - math.cos(wp * t)))
+    # D_x = -(Larmor / (Debye^2 c)) J0 / w_p sin(w_p t): back to zero after one period, uniform throughout
+    f = run.state(P.state_index["field"])
+    uniform = max(float(np.ptp(run.state(i)[c])) for i, _ in sp for c in range(5))
+    amp = P.ref["Larmor"] / (D * D * P.ref["lightspeed"]) * abs(J0) / wp
+    run.close()
+    return err, abs(float(f[0].mean())) / amp, uniform
+
+
+def check_cyclotron(make, B0=0.5):
+    cfg = problems.uniform_plasma_2d(8, "Lorentz", u0=1e-2, B0=B0)
+    P = config.Problem(cfg)
+    run = make(P)
+    errs = []
+    for nm in ("ion", "electron"):
+        i = P.state_index[nm]
+        g = cfg["states"][nm]["gas"]
+        r = g["charge"] / g["mass"]
+        wc = abs(r) * B0 / P.ref["Larmor"]
+        errs.append((i, r, wc))
+    # step so that the faster species (electrons) turns once in 400 steps
+    T = 2 * math.pi / max(e[2] for e in errs)
+    nsteps = 400
+    dt, t, err = T / nsteps, 0.0, 0.0
+    m0 = {i: float(run.state(i)[1].mean()) for i, _, _ in errs}
+    for _ in range(nsteps):
+        run.advance(dt)
+        t += dt
+        for i, r, wc in errs:
+            U = run.state(i)
+            mx, my = float(U[1].mean()) / m0[i], float(U[2].mean()) / m0[i]
+            # d(m)/dt = (rho r / Larmor) v x B with B = B0 e_z: rotation by -sign(r) w_c t
+            err = max(err, abs(mx - math.cos(wc * t)), abs(my + math.copysign(1.0, r) * math.sin(wc * t)))
+    f = run.state(P.state_index["field"])
+    untouched = float(np.abs(f[:3]).max())     # Lorentz: no back-reaction on the field (MFP_lorentz.cpp:60-198)
+    run.close()
+    return err, untouched
+
+
+def test_langmuir_oscillation_oracle(oracle):
+    err, d_back, uniform = check_langmuir(lambda P: OracleRunner(oracle, P))
+    assert err <= OSC_TOL and d_back <= 2 * OSC_TOL and uniform <= 1e-13, (err, d_back, uniform)
+    # the frequency scales with 1 / Debye = c / skin_depth, independently of Larmor (beta): other scalings, same bar
+    err, d_back, _ = check_langmuir(lambda P: OracleRunner(oracle, P), lightspeed=10.0, skin_depth=0.5, beta=0.3, mass_ratio=100.0)
+    assert err <= OSC_TOL and d_back <= 2 * OSC_TOL, (err, d_back)
+
+
+def test_cyclotron_rotation_oracle(oracle):
+    err, untouched = check_cyclotron(lambda P: OracleRunner(oracle, P))
+    assert err <= OSC_TOL and untouched == 0.0, (err, untouched)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [abi.FP_STRICT, abi.FP_FAST])
+def test_langmuir_and_cyclotron_gpu(mode):
+    mk = lambda P: GpuRunner(config.Problem(P.cfg, fp_mode=mode))
+    err, d_back, uniform = check_langmuir(mk)
+    assert err <= OSC_TOL and d_back <= 2 * OSC_TOL and uniform <= 1e-13, (err, d_back, uniform)
+    err, untouched = check_cyclotron(mk)
+    assert err <= OSC_TOL and untouched == 0.0, (err, untouched)
