@@ -10,11 +10,18 @@ ghost fill, CTU flux update of every state, source half step, CFL dt estimate
 (with the cross-rank min) — on synthetic analytic initial data already resident
 in HBM.  Weak scaling: every GPU owns an n x n block.  Rank 0 prints one JSON
 line.
+
+The K steps are timed `--reps` times (each block bracketed by a barrier and a
+device synchronisation, maximum over ranks); `value` / `ms_per_step` are those of
+the median block, all blocks are listed in `rep_ms_per_step`.  At N = 1 the same
+run also reports (extra keys): the same workload in STRICT arithmetic, the other
+BASELINE configurations that fit one GPU (KH 2048^2, the GEM block 4096 x 2048,
+RMI 256^3) with their own roofline entry, and the CPU baseline.
 """
 import argparse
 import json
-import math
 import os
+import statistics
 import sys
 import time
 
@@ -26,6 +33,9 @@ WORKLOAD_NOTE = {"ot2f_2d": "BASELINE configs[2]: 2D two-fluid Orszag-Tang, plas
                  "kh_2d": "BASELINE configs[1]: 2D KH hydro HLLC",
                  "rmi_3d": "BASELINE configs[4]: 3D two-fluid Richtmyer-Meshkov, plasma5 source",
                  "gem_2d": "BASELINE configs[3]: 2D GEM reconnection two-fluid + Maxwell, walls in y; 8 GPUs x 4096x2048 = 8192^2"}
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_ROUND = "r02"                         # profiles/<round>/pmc_<tag>.json: PMC traffic per launch of the kept profiles
+PROFILE_TAG = {("ot2f_2d", 4096): "ot2f_4096", ("kh_2d", 2048): "kh_2048", ("gem_2d", 4096): "gem_4096", ("rmi_3d", 256): "rmi3d_256"}
 
 
 def block_cells(workload, n):
@@ -33,7 +43,6 @@ def block_cells(workload, n):
     if workload == "gem_2d":
         return [n, n // 2]
     return [n] * (3 if workload == "rmi_3d" else 2)
-HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def build_problem(workload, n, grid, fp_mode, corner_transport=True):
@@ -63,15 +72,16 @@ def build_problem(workload, n, grid, fp_mode, corner_transport=True):
 
 
 def cpu_baseline(workload, seconds=12.0):
-    """The CPU restatement (oracle/, kind 'port') timed on this host's cores on a
-    bounded sample of the same workload: 384^2 cells in 32^2 boxes (the
-    reference's amr.max_grid_size in its shipped inputs), whole steps until
-    `seconds` of wall time have been spent."""
+    """The CPU restatement (oracle/, kind 'port', g++ -O3 without fast-math) timed on this host's cores on a
+    bounded sample of the same workload: 384^2 cells in 32^2 boxes (the reference's amr.max_grid_size in its
+    shipped inputs), whole steps until `seconds` of wall time have been spent.  Threads = the cores this job
+    may use: OMP_NUM_THREADS where the harness sets it (16 per GPU on the box), else every core of the host."""
     from oracle import oracle as O
     from cerberus_amd import abi
     n = 384
     P = build_problem(workload, n, [1, 1, 1], abi.FP_STRICT)
-    threads = max(1, min(16, os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    visible = os.cpu_count() or 1
+    threads = max(1, min(visible, int(os.environ.get("OMP_NUM_THREADS", str(visible)))))
     O.lib().orc_set_threads(threads)
     sim = O.OracleSim(P, max_grid_size=32)
     dt = sim.est_time_step()
@@ -86,6 +96,7 @@ def cpu_baseline(workload, seconds=12.0):
             break
     el = time.perf_counter() - t0
     out = {"value": n * n * steps / el, "unit": "cell-updates/s", "cores": threads, "kind": "port",
+           "host_cpus_visible": visible, "compiler": "g++ -O3 -ffp-contract=off -fopenmp (oracle/Makefile)",
            "sample": f"{workload} {n}x{n}, max_grid_size 32, {steps} steps, {el:.1f} s"}
     # the same port on one core (SURVEY.md §8d asks for both figures): a few steps of a 192^2 sample
     O.lib().orc_set_threads(1)
@@ -99,7 +110,27 @@ def cpu_baseline(workload, seconds=12.0):
         sim.advance(dt)
         s1 += 1
     out["one_core_value"] = n1 * n1 * s1 / (time.perf_counter() - t0)
+    O.lib().orc_set_threads(threads)
     return out
+
+
+def pmc_file(workload, n):
+    tag = PROFILE_TAG.get((workload, n))
+    if not tag:
+        return {}, None
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"pmc_{tag}.json")
+    if not os.path.exists(path):
+        return {}, None
+    return json.load(open(path)), os.path.relpath(path, ROOT)
+
+
+def pmc_of(pmc, *subs):
+    """entry of the kept PMC summary whose kernel name contains every substring (largest traffic first)"""
+    best = None
+    for k, e in pmc.items():
+        if all(s in k for s in subs) and (best is None or e.get("hbm_bytes_per_launch", 0) > best.get("hbm_bytes_per_launch", 0)):
+            best = e
+    return best
 
 
 def main():
@@ -107,13 +138,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
     ap.add_argument("--workload", default="ot2f_2d", choices=sorted(ALGO_BYTES))
     ap.add_argument("--n", "--cells", dest="n", type=int, default=4096, help="cells per side of the per-GPU block")
     ap.add_argument("--fp", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--tiled-hydro", action="store_true", help="diagnostic: LDS-tiled hydro CTU kernel instead of the wave-marching one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (profiling runs): no STRICT / other-workload legs")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (profiling runs): no STRICT / other-workload legs, one timed block")
+    ap.add_argument("--extras-512", action="store_true", help="also RMI 512^3 (BASELINE configs[4] at full size; ~2 min of host-side set-up)")
     ap.add_argument("--rehearse", action="store_true",
                     help="diagnostic: run the N-rank path on ONE GPU (all ranks on cuda:0, gloo with host-staged halos); not a measurement")
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2],
@@ -136,12 +169,17 @@ def main():
     if args.rehearse:
         local = 0
     torch.cuda.set_device(local)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        one = torch.ones(1, dtype=torch.int64, device="cpu" if args.rehearse else "cuda")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)     # the collective backend really spans `world` ranks
+        ranks_seen = int(one.item())
+    reps = 1 if args.no_extras else max(1, args.reps)
 
     def hbm_copy_gbs():
         """attainable HBM bandwidth of this device: a 1 GiB device-to-device copy (read + write bytes)"""
@@ -157,100 +195,155 @@ def main():
         torch.cuda.synchronize()
         return 10 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-    fp_mode = abi.FP_FAST if args.fp == "fast" else abi.FP_STRICT
-    dim = 3 if args.workload == "rmi_3d" else 2
-    grid = block_grid(dim, world)
-    P = build_problem(args.workload, args.n, grid, fp_mode, not args.no_corner_transport)
-    m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=(3 if args.tiled_hydro else not args.no_fused),
-            exchange_device=("cpu" if args.rehearse and world > 1 else None), overlap=args.overlap)
-    m.init_data()
-
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    m.run(args.warmup)
-    fused = m.last_advance_fused()
-    sync()
-    m.profile_enable(True)
-    for s in range(4):
-        m.profile_read(s)
-    t0 = time.perf_counter()
-    m.run(args.steps)
-    sync()
-    el = time.perf_counter() - t0
-    prof = [m.profile_read(s) for s in range(4)]
-    m.profile_enable(False)
+    def measure(workload, n, fp, steps, warmup, nrep, copy_gbs):
+        """One workload on this process group: `nrep` timed blocks of `steps` steps after `warmup` steps.
+        Returns the JSON fragment (value, ms_per_step, roofline, kernel times)."""
+        fp_mode = abi.FP_FAST if fp == "fast" else abi.FP_STRICT
+        dim = 3 if workload == "rmi_3d" else 2
+        grid = block_grid(dim, world)
+        P = build_problem(workload, n, grid, fp_mode, not args.no_corner_transport)
+        m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=(3 if args.tiled_hydro else not args.no_fused),
+                exchange_device=("cpu" if args.rehearse and world > 1 else None), overlap=args.overlap)
+        m.init_data()
+        m.run(warmup)
+        fused = m.last_advance_path()
+        sync()
+        m.profile_enable(True)
+        for s in range(4):
+            m.profile_read(s)
+        m.host_times(reset=True)
+        blocks = []
+        for _ in range(nrep):
+            sync()
+            t0 = time.perf_counter()
+            m.run(steps)
+            sync()
+            el = time.perf_counter() - t0
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            blocks.append(float(t.item()))
+        prof = [m.profile_read(s) for s in range(4)]
+        m.profile_enable(False)
+        host = m.host_times()
+        m.close()
+        el = statistics.median(blocks)
+        tsteps = steps * nrep
+        blk = block_cells(workload, n)
+        cells = 1
+        for v in blk:
+            cells *= v
+        res = {"value": cells * world * steps / el, "ms_per_step": el / steps * 1e3,
+               "rep_ms_per_step": [b / steps * 1e3 for b in blocks],
+               "hbm_roofline_frac_whole_step": ALGO_BYTES[workload] * cells * steps / el / 1e9 / HBM_PEAK_GBS,
+               "kernel_ms_per_step": {"ctu_hydro": prof[0][1] / tsteps, "ctu_field": prof[1][1] / tsteps,
+                                      "source_rk2": prof[2][1] / tsteps, "ghost_fill": prof[3][1] / tsteps},
+               "fused_path": fused, "fp_mode": fp,
+               "workload": f"{workload} {'x'.join(str(v) for v in blk)} per GPU ({WORKLOAD_NOTE[workload]})",
+               "process_grid": grid[:dim], "global_cells": list(P.n_cell[:dim]), "time_integration": P.scheme, "cfl": P.cfl}
+        if world > 1:
+            res["host_ms_per_step"] = {k: v / tsteps * 1e3 for k, v in host.items()}
+        if rank != 0:
+            return res
+        # roofline of the dominant kernel family.  Candidates: the fused CTU update of one hydro state (5 comps
+        # read + written: 80 B per cell and launch) and the field's update, which in the fused Strang step also
+        # applies the second source half step to all three states (20 comps read + written: 320 B per cell; 160 B
+        # when the source epilogue is off).  The family with more time per step is `roofline`, the other
+        # `roofline_other`.  achieved = algorithmic bytes per launch / mean launch time (HIP events on the
+        # library's stream); in 3-D a "launch" of the field family is its plane-tile launches of one step together.
+        pmc, pmc_path = pmc_file(workload, n) if fp == "fast" else ({}, None)
 
-    t = torch.tensor([el], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
-
-    blk = block_cells(args.workload, args.n)
-    cells_per_gpu = 1
-    for v in blk:
-        cells_per_gpu *= v
-    total_cells = cells_per_gpu * world
-    value = total_cells * args.steps / el
-
-    out = None
-    if rank == 0:
-        # roofline of the dominant kernel.  Candidates: the fused CTU update of one hydro state (5 comps
-        # read + written: 80 B per cell) and, in the 2-D two-fluid workloads, the field's CTU launch, which
-        # also applies the second source half step to all three states (20 comps read + written: 320 B per
-        # cell; 160 B when the source epilogue is off).  The one with more time per step is reported as
-        # `roofline`, the other as `roofline_other`.
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        tj = json.load(open(tpath)).get(f"{args.workload}:{args.n}", {}) if os.path.exists(tpath) else {}
-        copy_gbs = hbm_copy_gbs()
-
-        def roof_of(slot, bytes_per_cell, kname, traffic_key):
+        def roof_of(slot, bytes_per_cell, kname, per_update, pmc_subs):
             launches, ms = prof[slot]
             if not launches:
                 return None
-            algo = float(bytes_per_cell) * cells_per_gpu
-            achieved = algo / (ms / launches * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": tj.get(traffic_key), "attainable_copy_GBs": copy_gbs,
-                    "frac_of_attainable": achieved / copy_gbs, "algorithmic_bytes_per_launch": algo,
-                    "avg_launch_ms": ms / launches, "launches": launches, "ms_per_step": ms / args.steps}
+            updates = launches / per_update
+            algo = float(bytes_per_cell) * cells
+            achieved = algo / (ms / updates * 1e-3) / 1e9
+            e = None
+            traffic = None
+            for subs in pmc_subs:
+                q = pmc_of(pmc, *subs)
+                if q and "hbm_bytes_per_launch" in q:
+                    traffic = (traffic or 0.0) + q["hbm_bytes_per_launch"]
+                    e = e or q
+            r = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_path,
+                 "attainable_copy_GBs": copy_gbs, "frac_of_attainable": achieved / copy_gbs,
+                 "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms / updates, "launches": launches,
+                 "ms_per_step": ms / tsteps}
+            if e and "valu_busy" in e:
+                r["fp64_valu_busy"] = e["valu_busy"]
+            return r
 
         if dim == 3:
-            hname = "k_ctu3d<HydroF<minmod,HLLC>> (z-marching fused CTU update of one hydro state)"
-        elif args.tiled_hydro:
-            hname = "k_ctu2d<HydroF<minmod,HLLC>> (LDS-tiled fused CTU update of one hydro state)"
+            hroof = roof_of(0, 80, "k_ctu3d<HydroF<minmod,HLLC>> (z-marching fused CTU update of one hydro state)", 1, [("k_ctu3d",)])
+            per = prof[1][0] / tsteps if prof[1][0] else 1
+            epilogue = prof[2][0] == tsteps
+            froof = roof_of(1, 320 if epilogue else 160,
+                            "3-D field CTU update, all plane-tile launches of one step" + (" + Strang source stage C of both species" if epilogue else ""),
+                            per, [("k_f3d_xy", " 1,"), ("k_f3d_z", " 1,"), ("k_f3d_xy", " 2,"), ("k_f3d_z", " 2,")])
         else:
-            hname = "k_ctu_march<HydroF<minmod,HLLC>> (wave-marching fused CTU update of one hydro state)"
-        roof = roof_of(0, 80, hname, "ctu_hydro_bytes_per_launch")
-        roof_other = None
-        if dim == 2 and prof[1][0] == args.steps:   # one field launch per step (no interior / frame split)
-            epilogue = prof[2][0] == args.steps     # one separate source launch per step: stage C is in the field kernel
-            fname = ("k_ctu2d<FieldF<O6>,SRC=2> (LDS-tiled fused CTU update of the field state + Strang source stage C of both species)"
-                     if epilogue else "k_ctu2d<FieldF<O6>> (LDS-tiled fused CTU update of the field state)")
-            froof = roof_of(1, 320 if epilogue else 160, fname, "ctu_field_bytes_per_launch")
-            if froof and roof and froof["ms_per_step"] > roof["ms_per_step"]:
-                roof, roof_other = froof, roof
-            else:
-                roof_other = froof
-        step_bytes = ALGO_BYTES[args.workload] * cells_per_gpu
+            hname = ("k_ctu2d<HydroF<minmod,HLLC>> (LDS-tiled fused CTU update of one hydro state)" if args.tiled_hydro
+                     else "k_ctu_march<HydroF<minmod,HLLC>> (wave-marching fused CTU update of one hydro state)")
+            hroof = roof_of(0, 80, hname, 1, [("k_ctu2d<fast::HydroF",) if args.tiled_hydro else ("k_ctu_march",)])
+            froof = None
+            if prof[1][0] == tsteps:   # one field launch per step (no interior / frame split)
+                epilogue = prof[2][0] == tsteps     # one separate source launch per step: stage C is in the field kernel
+                fname = ("k_ctu2d<FieldF<O6>,SRC=2> (LDS-tiled fused CTU update of the field state + Strang source stage C of both species)"
+                         if epilogue else "k_ctu2d<FieldF<O6>> (LDS-tiled fused CTU update of the field state)")
+                froof = roof_of(1, 320 if epilogue else 160, fname, 1, [("k_ctu2d<fast::FieldF",)])
+        roof, other = hroof, froof
+        if froof and hroof and froof["ms_per_step"] > hroof["ms_per_step"]:
+            roof, other = froof, hroof
+        res["roofline"], res["roofline_other"] = roof, other
+        return res
+
+    copy_gbs = hbm_copy_gbs() if rank == 0 else None
+    main_res = measure(args.workload, args.n, args.fp, args.steps, args.warmup, reps, copy_gbs)
+
+    out = None
+    if rank == 0:
         out = {
             "metric": "cell-updates/s (fp64, single-fluid hydro)" if args.workload == "kh_2d"
                       else "cell-updates/s (fp64, five-moment 2-fluid+Maxwell)",
-            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload} {'x'.join(str(v) for v in blk)} per GPU ({WORKLOAD_NOTE[args.workload]})",
-                       "process_grid": grid[:dim], "global_cells": list(P.n_cell[:dim]), "fp_mode": args.fp,
-                       "fused_kernels": bool(fused), "corner_transport": not args.no_corner_transport, "time_integration": P.scheme, "cfl": P.cfl},
-            "hbm_roofline_frac_whole_step": (step_bytes * args.steps / (el)) / 1e9 / HBM_PEAK_GBS,
-            "roofline": roof, "roofline_other": roof_other,
-            "kernel_ms_per_step": {"ctu_hydro": prof[0][1] / args.steps, "ctu_field": prof[1][1] / args.steps,
-                                   "source_rk2": prof[2][1] / args.steps, "ghost_fill": prof[3][1] / args.steps},
+            "value": main_res["value"], "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic", "reps": reps, "rep_ms_per_step": main_res["rep_ms_per_step"],
+            "ranks_seen": ranks_seen,
+            "config": {"workload": main_res["workload"], "process_grid": main_res["process_grid"],
+                       "global_cells": main_res["global_cells"], "fp_mode": args.fp,
+                       "fused_kernels": bool(main_res["fused_path"]), "corner_transport": not args.no_corner_transport,
+                       "time_integration": main_res["time_integration"], "cfl": main_res["cfl"]},
+            "hbm_roofline_frac_whole_step": main_res["hbm_roofline_frac_whole_step"],
+            "roofline": main_res["roofline"], "roofline_other": main_res["roofline_other"],
+            "kernel_ms_per_step": main_res["kernel_ms_per_step"],
         }
-    m.close()
+        if "host_ms_per_step" in main_res:
+            out["host_ms_per_step"] = main_res["host_ms_per_step"]
+    # ---- extra legs: single GPU only (they are not part of the scaling contract)
+    if world == 1 and not args.no_extras:
+        keep = ("value", "ms_per_step", "rep_ms_per_step", "hbm_roofline_frac_whole_step", "kernel_ms_per_step", "roofline",
+                "roofline_other", "workload", "fp_mode")
+        other_fp = "strict" if args.fp == "fast" else "fast"
+        r = measure(args.workload, args.n, other_fp, max(5, args.steps // 2), 2, 3, copy_gbs)
+        out[other_fp] = {k: r[k] for k in keep if k in r}
+        others = {}
+        legs = [("kh_2d", 2048, 40), ("gem_2d", 4096, 10), ("rmi_3d", 256, 5)]
+        if args.extras_512:
+            legs.append(("rmi_3d", 512, 3))
+        for w, n, st in legs:
+            if (w, n) == (args.workload, args.n):
+                continue
+            r = measure(w, n, args.fp, st, 2, 3, copy_gbs)
+            others[f"{w}:{n}"] = {k: r[k] for k in keep if k in r}
+        out["other_workloads"] = others
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

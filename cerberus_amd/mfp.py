@@ -47,6 +47,7 @@ class MFP:
         p = self.p
         self.rank, self.world, self.pg = rank, world, pg
         self._stream = int(stream or 0)
+        self._host_t = {"exchange": 0.0, "dt_reduce": 0.0}
         self.grid = block_grid(p.dim, world)
         self.coords = rank_coords(rank, self.grid)
         self.block_n, self.block_lo = [1, 1, 1], [0, 0, 0]
@@ -222,6 +223,15 @@ class MFP:
         """0: staged kernels, 1: tiled fused kernels, 2: gather kernels (1-D / 3-D, or forced with fused=2)."""
         return int(self.L.cmfp_last_advance_fused(self.h))
 
+    def host_times(self, reset=False):
+        """Host seconds spent inside the exchange and dt-reduce hooks (ranks > 1): enqueue cost on the host,
+        not device time; everything in them is asynchronous with a device-to-device transport."""
+        out = dict(self._host_t)
+        if reset:
+            for k in self._host_t:
+                self._host_t[k] = 0.0
+        return out
+
     def profile_enable(self, on=True):
         self._chk(self.L.cmfp_profile_enable(self.h, int(on)))
 
@@ -309,10 +319,14 @@ class MFP:
         """cmfp_dt_reduce_fn: all-reduce(MIN) of the device-resident dt (ReduceRealMin, MFP_timestep.cpp:18),
         enqueued in stream order: no host synchronisation with RCCL."""
         try:
+            import time
             import torch
             import torch.distributed as dist
+            t0 = time.perf_counter()
             with self._stream_ctx():
-                return self._dt_reduce_body(torch, dist, ptr)
+                rc = self._dt_reduce_body(torch, dist, ptr)
+            self._host_t["dt_reduce"] += time.perf_counter() - t0
+            return rc
         except Exception as e:  # never let an exception cross the C boundary
             import traceback
             traceback.print_exc()
@@ -338,9 +352,13 @@ class MFP:
         Buffers 0/1 = send lo/hi, 2/3 = recv lo/hi.  s = CMFP_ALL_STATES (-1): the
         faces of every state travel back to back in one message per neighbour."""
         try:
+            import time
             import torch.distributed as dist
+            t0 = time.perf_counter()
             with self._stream_ctx():
-                return self._exchange_body(dist, s, d)
+                rc = self._exchange_body(dist, s, d)
+            self._host_t["exchange"] += time.perf_counter() - t0
+            return rc
         except Exception as e:  # never let an exception cross the C boundary
             import traceback
             traceback.print_exc()

@@ -6,7 +6,7 @@
 // written from a reading of the reference sources; every function cites the
 // reference file:line it follows and keeps that code's expression order and
 // loop structure (staged FAB-by-FAB pipeline, separate prim / face / flux
-// arrays).  It is compiled by oracle/Makefile with g++ -O2 -ffp-contract=off.
+// arrays).  It is compiled by oracle/Makefile with g++ -O3 -ffp-contract=off.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 // load this library.  Nothing under cerberus_amd/ includes, links or calls it.

@@ -30,6 +30,7 @@ class HostHaloMFP(MFP):
         self.block_n = [problem.n_cell[d] // self.grid[d] for d in range(3)]
         self.block_lo = [self.coords[d] * self.block_n[d] for d in range(3)]
         self._bufs = {}
+        self._host_t = {"exchange": 0.0, "dt_reduce": 0.0}
         self._exchange_device = "cpu"
         self.p.periodic = periodic
         ny, nx = self.block_n[1], self.block_n[0]

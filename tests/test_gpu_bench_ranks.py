@@ -1,0 +1,59 @@
+"""bench.py's own N-rank code path under the driver's launcher, rehearsed on one GPU: the exact command line
+of the scaling run (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)
+with `--rehearse` (all ranks on cuda:0, gloo with host-staged halos, because RCCL refuses two ranks on one
+device).  Checks the JSON contract, that the collective backend saw N ranks, and that the split-block
+kernels (interior / frame launches, batched exchange, device-resident dt with the cross-rank minimum) ran.
+The RCCL transport itself (device buffers, N > 1) cannot run on a one-GPU box and stays unverified here."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(nranks, extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--rehearse",
+           "--no-cpu-baseline", "--reps", "2"] + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]        # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("nranks,extra,cells", [
+    (2, ["--workload", "ot2f_2d", "--cells", "512", "--steps", "3", "--warmup", "1"], 512 * 512),
+    (4, ["--workload", "ot2f_2d", "--cells", "256", "--steps", "2", "--warmup", "1"], 256 * 256),
+    (2, ["--workload", "gem_2d", "--cells", "512", "--steps", "3", "--warmup", "1"], 512 * 256),
+    (2, ["--workload", "rmi_3d", "--cells", "64", "--steps", "2", "--warmup", "1"], 64 ** 3),
+])
+def test_bench_n_rank_path(nranks, extra, cells):
+    out = _run(nranks, extra)
+    steps = int(extra[extra.index("--steps") + 1])
+    assert out["n_gpus"] == nranks and out["ranks_seen"] == nranks
+    assert out["steps"] == steps and out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["unit"] == "cell-updates/s" and out["dtype"] == "f64"
+    assert out["config"]["fused_kernels"] is True
+    grid = out["config"]["process_grid"]
+    n = 1
+    for g in grid:
+        n *= g
+    assert n == nranks
+    # value = cells of all ranks x steps / time of the median block
+    assert abs(out["value"] - cells * nranks * steps / (out["ms_per_step"] * steps * 1e-3)) <= 1e-6 * out["value"]
+    assert len(out["rep_ms_per_step"]) == 2 and out["ms_per_step"] > 0
+    assert out["host_ms_per_step"]["exchange"] > 0          # the exchange hook ran on the split block
+    assert out["cpu_baseline"] is None                       # rank 0 at N = 1 only

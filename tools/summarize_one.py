@@ -37,6 +37,11 @@ for d in ("fetch", "write", "sq"):
         k, c = r["Kernel_Name"], r["Counter_Name"]
         acc[k][c] += float(r["Counter_Value"])
         cnt[k][c] += 1
+dur = {}   # average launch duration (ns) per kernel from the kernel-trace pass
+f = first(f"prof_{tag}_stats/**/*kernel_stats.csv")
+if f:
+    for r in csv.DictReader(open(f)):
+        dur[r["Name"]] = float(r["AverageNs"])
 res = {}
 for k in acc:
     if not any(s in k for s in ("k_ctu", "k_f3d", "k_source", "k_g_", "k_fill", "k_pack", "k_proj", "k_fld")):
@@ -51,7 +56,14 @@ for k in acc:
         e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
     if "SQ_WAVES" in e and e["SQ_WAVES"]:
         e["valu_insts_per_wave"] = e.get("SQ_INSTS_VALU", 0) / e["SQ_WAVES"]
+    if k in dur:
+        e["avg_launch_ns"] = dur[k]
+        if "SQ_ACTIVE_INST_VALU" in e:
+            # VALU-busy fraction of the launch: the counter advances once per 4 cycles a SIMD issues VALU work;
+            # 256 CUs x 4 SIMDs at 2.4 GHz (the recipe of profiles/r01/README.md)
+            e["valu_busy"] = e["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * dur[k] * 2.4)
     res[k[:140]] = e
 json.dump(res, open(os.path.join(out, f"pmc_{tag}.json"), "w"), indent=1, sort_keys=True)
 for k, e in sorted(res.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0)):
-    print(k[:100], "GB/launch", round(e.get("hbm_bytes_per_launch", 0) / 1e9, 3), "valu/wave", round(e.get("valu_insts_per_wave", 0)))
+    print(k[:100], "GB/launch", round(e.get("hbm_bytes_per_launch", 0) / 1e9, 3), "valu/wave", round(e.get("valu_insts_per_wave", 0)),
+          "ms", round(e.get("avg_launch_ns", 0) / 1e6, 3), "valu_busy", round(e.get("valu_busy", 0), 2))
