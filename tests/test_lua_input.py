@@ -1,0 +1,165 @@
+"""Reader of the reference's input files (cerberus_amd/lua_input.py): the Lua subset interpreter on an
+authored script that uses the constructs of the shipped problem definitions, the ParmParse part, and - where the
+reference tree is present (this container; it does not travel to the GPU box) - the shipped inputs
+Exec/testing/Thermal-RMI and Exec/testing/Braginskii_Riemann_2F loaded unchanged, checked against values worked
+out independently from their text."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from cerberus_amd import config, lua_input, problems
+
+REF = "/root/reference/Exec/testing"
+
+SCRIPT = r"""
+-- comment
+--[[ long
+comment ]]
+gam = 5 / 3
+local hidden = 7
+shock_x = -0.2
+B = { 0, 0, 0 }
+axis_beta = { 0, 2, 0 }
+beta = 1
+for i, b in ipairs(axis_beta) do
+  if b > 0 then B[i] = math.sqrt(2 * beta / b) end
+end
+local function issmall(x) return x < 2 ^ -28 end
+function pick(x, L, R)
+  if x <= shock_x then return L elseif x > 10 then return -1 else return R end
+end
+function sgn(x) return x < 0 and -1 or 1 end
+count = 0
+for k = 10, 1, -3 do count = count + k end          -- 10 + 7 + 4 + 1
+t = {}
+table.insert(t, 'a'); table.insert(t, 'b'); table.insert(t, 1, 'z')
+joined = table.concat(t, ',')
+n = #t
+w = 0
+while w < 5 do w = w + 2 end
+repeat w = w - 1 until w < 3
+s = 'it' .. "'s " .. 2
+function multi() return 1, 2, 3 end
+a, b, c, d = multi()
+packed = { multi(), multi() }
+fmt = string.format('%d-%5.2f-%s', 3, 2.5, 'x')
+cfl = 0.3
+time_integration_scheme = 'strang'
+lightspeed = 20.0
+skin_depth = 1.0
+states = {
+  ion = { type = 'hydro', gas = { type = 'thermally_perfect', mass = 1.0, charge = 1, gamma = gam },
+          reconstruction = 'minmod', flux = 'HLLC', refinement = { name = 'hydro_gradient', rho = 0.1 },
+          value = { rho = function(dat) return pick(dat['x'], 2.0, 1.0) end, x_vel = 0.5, p = function(dat) return 1 + dat.y end } },
+  field = { type = 'field', reconstruction = 'O6', flux = 'RankineHugoniot', value = { y_B = B[2] } },
+  dust = { type = 'tracer', particles = { { 0.1, 0.2 } } },
+}
+actions = {
+  fluxes = { type = 'CTU', corner_transport = true, states = { 'ion' } },
+  em = { type = 'CTU', corner_transport = true, states = { 'field' } },
+  lor = { type = 'Lorentz', states = { 'ion', 'field' } },
+  clean = { type = 'elliptic', projection = 1, state = 'field' },
+}
+"""
+GEOM = {"dim": 2, "n_cell": [8, 4], "prob_lo": [-1.0, 0.0], "prob_hi": [1.0, 1.0], "is_periodic": [0, 1]}
+
+
+def test_interpreter_subset():
+    cfg, it = lua_input.load_lua(SCRIPT, dict(GEOM))
+    G = it.globals
+    assert G.get("hidden") is None and G.get("count") == 22 and G.get("joined") == "z,a,b" and G.get("n") == 3
+    assert G.get("w") == 2 and G.get("s") == "it's 2.0" and (G.get("a"), G.get("b"), G.get("c"), G.get("d")) == (1, 2, 3, None)
+    assert lua_input.to_python(G.get("packed"), it) == [1, 1, 2, 3]          # only the last call expands
+    assert G.get("fmt") == "3- 2.50-x"
+    assert lua_input.to_python(G.get("B"), it) == [0, 1.0, 0]
+    assert it.call_value(G.get("sgn"), [-3.0]) == [-1] and it.call_value(G.get("pick"), [11.0, 5, 6]) == [-1]
+    assert sorted(cfg["states"]) == ["field", "ion"] and sorted(cfg["actions"]) == ["em", "fluxes", "lor"]
+    assert any("dust" in s for s in cfg["_ignored"]) and any("clean" in s for s in cfg["_ignored"])
+    assert any("refinement" in s for s in cfg["_ignored"])
+    P = config.Problem(cfg)
+    U = P.initial_data(P.state_index["ion"])
+    x = P.cell_centres()["x"][0]
+    assert np.array_equal(U[0, 0], np.where(x <= -0.2, 2.0, 1.0))
+    F = P.initial_data(P.state_index["field"])
+    assert np.all(F[4] == 1.0) and np.all(F[8] == 1.0) and np.all(F[6] == 0.0)
+    assert cfg["states"]["ion"]["value"]["rho"].uses_time is False
+    with pytest.raises(lua_input.LuaError):
+        lua_input.load_lua("x = nil + 1", dict(GEOM))
+    with pytest.raises(lua_input.LuaError):
+        lua_input.load_lua("states = { a = { type='hydro' } } actions = { f = { type='CTU', states={'b'} } }", dict(GEOM))
+
+
+def test_parmparse_and_dofile(tmp_path):
+    (tmp_path / "problem.lua").write_text(SCRIPT)
+    (tmp_path / "case.inputs").write_text(
+        "# comment\nmax_step  = 1000\nstop_time = 0.3   # trailing\ngeometry.is_periodic = 0 1 1\n"
+        "geometry.coord_sys   = 0\ngeometry.prob_lo     =     -4 0.0 0.0\ngeometry.prob_hi     =     4 1.0 1.0\n"
+        "amr.n_cell           =     64 8\namr.plot_file = run.plt\n\nmfp.lua = \"\ndofile('problem.lua')\ncfl = 0.25\n\"\n")
+    cfg, info = lua_input.load_inputs(str(tmp_path / "case.inputs"))
+    assert cfg["dim"] == 2 and cfg["n_cell"] == [64, 8] and cfg["prob_lo"] == [-4.0, 0.0] and cfg["is_periodic"] == [0, 1]
+    assert cfg["cfl"] == 0.25 and info["stop_time"] == 0.3 and info["max_step"] == 1000
+    P = config.Problem(cfg)
+    assert P.state_names == ["field", "ion"] and P.action_names == ["em", "fluxes", "lor"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not present on this machine")
+def test_reference_thermal_rmi_loads_unchanged(oracle):
+    """Exec/testing/Thermal-RMI/TRMI.inputs + problem_definition.lua:1-323, as shipped"""
+    cfg, info = lua_input.load_inputs(os.path.join(REF, "Thermal-RMI", "TRMI.inputs"), n_cell=[128, 16])
+    assert sorted(cfg["states"]) == ["electron", "field", "ion"]
+    assert sorted(cfg["actions"]) == ["em_fluxes", "hydro_fluxes", "plasma"]
+    for dropped in ("electron_tracer", "ion_tracer", "divergence_cleaning", "tracer_electron", "tracer_ion"):
+        assert any(dropped in s for s in info["ignored"]), dropped
+    ion, ele, fld = cfg["states"]["ion"], cfg["states"]["electron"], cfg["states"]["field"]
+    assert ion["gas"] == {"type": "thermally_perfect", "mass": 1.0, "charge": 1, "gamma": 5 / 3}
+    assert ele["gas"]["mass"] == 0.01 and ele["gas"]["charge"] == -1.0
+    assert (ion["reconstruction"], ion["flux"], fld["reconstruction"], fld["flux"]) == ("minmod", "HLLC", "O6", "RankineHugoniot")
+    assert cfg["actions"]["plasma"] == {"type": "plasma5", "solver": "explicit", "states": ["ion", "electron", "field"]}
+    assert cfg["actions"]["hydro_fluxes"]["corner_transport"] is True
+    assert (cfg["cfl"], cfg["lightspeed"], cfg["skin_depth"], cfg["beta"], cfg["time_integration_scheme"]) == (0.3, 20.0, 1.0, 1.0, "strang")
+    # the initial data against the formulas of problem_definition.lua:18-38, 106-137 worked out here
+    gam, M, p1 = 5 / 3, 2.0, 0.5
+    p0 = p1 * (1 + ((2 * gam) / (gam + 1)) * (M ** 2 - 1))
+    rho0 = 1.0 / (1 - (2 / (gam + 1)) * (1 - 1 / M ** 2))
+    a0, a1 = math.sqrt(gam * p0 / rho0), math.sqrt(gam * p1 / 1.0)
+    u0 = M * a1 - a0 * math.sqrt(((gam - 1) * M ** 2 + 2) / (2 * gam * M ** 2 - (gam - 1)))
+    P = config.Problem(cfg)
+    U = P.initial_data(P.state_index["ion"])
+    dat = P.cell_centres()
+    x, y = dat["x"][0], dat["y"][0]
+    post = x <= -0.2
+    assert np.allclose(U[0, 0][post], rho0, rtol=1e-14) and np.allclose((U[1, 0] / U[0, 0])[post], u0, rtol=1e-13)
+    at = (10.0 * 1.0 - 9.0 * 3.0) / (10.0 * (3.0 - 1.0))
+    slope = (2.0 / 0.01) * math.atanh(at)
+    centre = 0.0 + 0.1 * np.cos(2 * math.pi * y)
+    expect = -((np.tanh(-slope * (x - centre)) - 1.0) / 2.0) * (1.0 - 3.0) + 3.0
+    assert np.allclose(U[0, 0][~post], expect[~post], rtol=1e-9)       # the script carries its own tanh / atanh
+    E = P.initial_data(P.state_index["electron"])
+    assert np.allclose(E[0], 0.01 * U[0], rtol=1e-14)
+    # and it runs: a few steps of the restatement on the loaded problem (hydro + Maxwell + plasma5, outflow in x)
+    sim = oracle.OracleSim(P)
+    dts = sim.run(3)
+    assert all(d > 0 for d in dts) and np.isfinite(sim.get_state(0)).all()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not present on this machine")
+def test_reference_brio_wu_matches_the_authored_config():
+    """Exec/testing/Braginskii_Riemann_2F as shipped, with the substitution SURVEY.md section 8(d) lists
+    (BraginskiiCTU -> CTU, no elliptic action): the same problem as problems.brio_wu_two_fluid_1d, which was
+    written from the same file by hand - descriptors and initial data identical."""
+    cfg, info = lua_input.load_inputs(os.path.join(REF, "Braginskii_Riemann_2F", "Riemann-2F-Braginskii.inputs"), n_cell=[512],
+                                      action_map={"BraginskiiCTU": "CTU"})
+    ref = problems.brio_wu_two_fluid_1d(512)
+    P, Q = config.Problem(cfg), config.Problem(ref)
+    assert P.state_names == Q.state_names and P.dim == 1 and P.prob_lo[0] == -2.0 and P.prob_hi[0] == 2.0
+    for k in ("lightspeed", "Larmor", "Debye"):
+        assert P.ref[k] == pytest.approx(Q.ref[k], rel=1e-14), k
+    assert P.cfl == Q.cfl and P.scheme == Q.scheme
+    for s in range(3):
+        assert np.array_equal(P.initial_data(s), Q.initial_data(s)), P.state_names[s]
+    for a, b in zip(P.state_descs(), Q.state_descs()):
+        assert (a.kind, a.reconstruction, a.flux, a.mass, a.charge, a.gamma) == (b.kind, b.reconstruction, b.flux, b.mass, b.charge, b.gamma)
+    kinds = sorted(cfg["actions"][n]["type"] for n in cfg["actions"])
+    assert kinds.count("CTU") >= 2 and "plasma5" in kinds
