@@ -95,7 +95,11 @@ class Problem:
         self.force_dt = float(cfg.get("force_dt", DEFAULTS["force_dt"]))   # MFP_timestep.cpp:8
         self.fp_mode = fp_mode
         self.state_names = sorted(cfg["states"].keys())       # get_sorted_keys, MFP_config.cpp:102
-        self.action_names = sorted(cfg.get("actions", {}).keys())  # :261
+        # `elliptic` actions act through apply_change only (MFP_advance.cpp:49): they are kept beside the actions
+        # of the hyperbolic update, in the same sorted order
+        acts = cfg.get("actions", {})
+        self.action_names = sorted(k for k in acts if acts[k]["type"] != "elliptic")  # :261
+        self.elliptic_names = sorted(k for k in acts if acts[k]["type"] == "elliptic")
         self.state_index = {n: i for i, n in enumerate(self.state_names)}
 
     # -- descriptors -----------------------------------------------------
@@ -226,6 +230,28 @@ class Problem:
             for j, v in enumerate(idx):
                 a.states[j] = v
         return arr
+
+    def elliptic_actions(self):
+        """[(field state index, [species state indices])] of the `elliptic` actions, sorted by name:
+        Elliptic::Elliptic (MFP_elliptic.cpp:31-68) and the species of the plasma5 actions associated with the
+        field (:700-712).  Only projection = 1 is built (the static-field solve is outside the path)."""
+        out = []
+        for name in self.elliptic_names:
+            ad = self.cfg["actions"][name]
+            if int(ad.get("projection", 0)) != 1:
+                raise NotImplementedError(f"action '{name}': only projection = 1 of 'elliptic' is built")
+            st = ad.get("state", "null")
+            if st == "null":
+                raise ValueError(f"Action '{name}' requires option 'state' to be defined.")
+            if self.cfg["states"][st]["type"] != "field":
+                raise ValueError(f"An invalid state has been defined for the '{name}' action")
+            species = []
+            for an in self.action_names:
+                a = self.cfg["actions"][an]
+                if a["type"] == "plasma5" and st in a["states"]:
+                    species += [self.state_index[n] for n in a["states"] if self.cfg["states"][n]["type"] == "hydro"]
+            out.append((self.state_index[st], species))
+        return out
 
     def n_comp(self, s):
         sd = self.cfg["states"][self.state_names[s]]

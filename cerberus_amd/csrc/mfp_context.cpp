@@ -6,6 +6,7 @@
 // compute entry point returns CMFP_ERR_NODEVICE.
 #include "../../include/cerberus_mfp.h"
 #include "mfp_types.h"
+#include "mfp_elliptic.h"
 
 #include <hip/hip_runtime.h>
 
@@ -90,6 +91,7 @@ struct cmfp_context {
     int* d_err = nullptr;
     double* d_dtbuf = nullptr;  // cmfp_advance_steps: device-resident dt + dt log
     int d_dtcap = 0;
+    cmfp_ell::Work ell;  // divergence projection scratch (cmfp_elliptic_project)
     bool no_alloc = false;  // inside cmfp_advance_steps_static: anything that would allocate fails instead
     unsigned long long* d_red = nullptr;  // one reduction word per state + per action
     double* d_part = nullptr;             // CMFP_RED_BLOCKS block partials per word
@@ -1075,6 +1077,7 @@ int cmfp_destroy(cmfp_context* c) {
     for (double* p : c->allocs) (void)hipFree(p);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_dtbuf) (void)hipFree(c->d_dtbuf);
+    cmfp_ell::release(c->ell);
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->d_part) (void)hipFree(c->d_part);
     delete c;
@@ -1467,6 +1470,34 @@ int cmfp_state_set_face_values(cmfp_context* c, int s, int dim, int side, int pr
     for (int d = 0; d < 3; ++d)
         for (int sd = 0; sd < 2; ++sd)
             for (int n = 0; n < CMFP_MAX_COMP; ++n) st.has_tables = st.has_tables || st.tab_cell[d][sd][n];
+    return CMFP_OK;
+}
+
+// Elliptic::project_divergence_field MFP_elliptic.cpp:667-782
+int cmfp_elliptic_project(cmfp_context* c, int fs, int n_species, const int* species) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (fs < 0 || fs >= (int)c->states.size() || c->states[fs].sp.kind != CMFP_STATE_FIELD)
+        return fail(c, CMFP_ERR_INVALID, "An invalid state has been defined for the 'elliptic' action");  // :66
+    if (n_species < 0 || n_species > 8 || (n_species && !species)) return fail(c, CMFP_ERR_INVALID, "bad species list");
+    if (const char* why = cmfp_ell::check(c->g, c->geom.is_periodic, c->split)) return fail(c, CMFP_ERR_INVALID, why);
+    cmfp_ell::ChargeArgs q;
+    std::memset(&q, 0, sizeof(q));
+    q.ns = n_species;
+    for (int n = 0; n < n_species; ++n) {
+        if (species[n] < 0 || species[n] >= (int)c->states.size() || c->states[species[n]].sp.kind != CMFP_STATE_HYDRO)
+            return fail(c, CMFP_ERR_INVALID, "elliptic: species must be hydro states");
+        q.rho[n] = c->states[species[n]].new_data;                                  // Density component
+        q.r[n] = c->states[species[n]].desc.charge / c->states[species[n]].desc.mass;
+    }
+    HIPCHK(c, cmfp_ell::setup(c->g, c->ell));
+    double* F = c->states[fs].new_data;
+    const long sc = c->g.sc;
+    q.ep = F + 9 * sc;
+    q.cd_scale = c->params.Larmor / (c->params.Debye * c->params.Debye * c->params.lightspeed);  // :688
+    cmfp_ell::project(c->g, c->ell, F + 3 * sc, F + 7 * sc, nullptr, c->stream);  // B with psi   :678-682
+    cmfp_ell::project(c->g, c->ell, F + 0 * sc, F + 6 * sc, &q, c->stream);       // D with phi   :775-780
+    std::fill(c->red_valid.begin(), c->red_valid.end(), 0);  // B changed: the cyclotron dt limit has to be taken again
     return CMFP_OK;
 }
 

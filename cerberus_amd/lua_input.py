@@ -1169,6 +1169,10 @@ def problem_from_lua(interp, geometry, action_map=None):
             d["type"] = t = action_map[t]
             d = {k: v for k, v in d.items() if k in ("type", "states", "corner_transport", "solver", "cross_sections")}
             d.setdefault("corner_transport", True)
+        if t == "elliptic" and int(d.get("projection", 0)) == 1 and all(geometry["is_periodic"][:geometry["dim"]]) \
+                and geometry["dim"] > 1 and d.get("state") in states:
+            actions[name] = d        # divergence projection: built for periodic domains
+            continue
         if t not in _ON_PATH_ACTIONS:
             ignored.append(f"actions.{name} (type '{t}')")
             continue

@@ -73,7 +73,9 @@ class MFP:
         self._chk(self.L.cmfp_set_overlap(self.h, int(overlap)))
         self.shape = tuple(self.block_n[::-1])
         self.time, self.dt, self.step = 0.0, None, 0
-        self._device_dt = bool(device_dt)
+        self._elliptic = p.elliptic_actions()
+        # with an apply_change action the step is not one enqueue-able unit: per-step driver
+        self._device_dt = bool(device_dt) and not self._elliptic
         self._time_bc = [s for s in range(self.n_states) if p.face_values_depend_on_time(s)]
         if self._time_bc and p.scheme != "strang":
             raise NotImplementedError("time-dependent boundary functions: 'strang' only (one flux evaluation at t + dt)")
@@ -165,6 +167,9 @@ class MFP:
         for s in self._time_bc:     # the flux stage of the Strang step is evaluated at time + dt (MFP_advance.cpp:208-217)
             self._upload_face_values(s, self.time + dt)
         self._chk(self.L.cmfp_advance(self.h, self.time, dt))
+        for fs, species in self._elliptic:     # act->apply_change (MFP_advance.cpp:49)
+            arr = (C.c_int * max(1, len(species)))(*species)
+            self._chk(self.L.cmfp_elliptic_project(self.h, fs, len(species), arr))
         self.time += dt
         self.step += 1
 

@@ -280,6 +280,16 @@ int cmfp_advance_steps(cmfp_context* ctx, double time, double dt0, int nsteps, d
  * it reads). */
 #define CMFP_STATIC_MAX_STEPS 4096
 int cmfp_advance_steps_static(cmfp_context* ctx, double time, double dt0, int nsteps, double* dts, double* dt_next);
+/* Elliptic::apply_change with projection = 1 (actions/MFP_elliptic.cpp:70-81): project_divergence_field
+ * (:667-782) = two calls of solve_divergence (:784-964) on the new-time data of `field_state` - the B field
+ * with psi, then the D field with phi and the cell-centred source -Larmor / (Debye^2 c) * rho_c / ep, rho_c
+ * the charge density of the n_species hydro states listed (the species of the plasma5 actions associated with
+ * the field, :700-765).  The host side calls it after cmfp_advance for every `elliptic` action, where the
+ * reference's MFP::advance loops apply_change (MFP_advance.cpp:49).  The reference solves with AMReX's nodal
+ * projection (MLNodeLaplacian + MLMG, third party, absent from its tree); here the same nodal operators are
+ * solved exactly by FFT on periodic blocks: every dimension periodic, a power of two of cells (<= 4096) per
+ * dimension, block = domain, 2-D or 3-D; otherwise CMFP_ERR_INVALID with the reason.  Parity unpinned. */
+int cmfp_elliptic_project(cmfp_context* ctx, int field_state, int n_species, const int* species_states);
 /* Uses hand-fused kernels inside cmfp_advance where available (default 1: the
  * LDS-tiled kernel for 2-D blocks, the tile-free gather kernels for 1-D and 3-D);
  * 2 forces the gather kernels in any dimensionality; 0 forces the stage-by-stage
