@@ -60,6 +60,9 @@ struct StateRT {
     double* tab_cell[3][2][CMFP_MAX_COMP] = {};
     double* tab_face[3][2][CMFP_MAX_COMP] = {};
     bool has_tables = false;
+    // field: the materials check (mu == ep == 1 everywhere) has been made for the data now in new_data;
+    // the ping-pong partner holds mu, ep too (the vacuum kernel neither reads nor rewrites them)
+    bool vac_known = false, alt_mat = false;
 };
 
 }  // namespace
@@ -89,6 +92,7 @@ struct cmfp_context {
     hipStream_t stream2 = nullptr;  // interior tiles run here while ghost cells are in flight on `stream`
     hipEvent_t ev_src = nullptr, ev_int = nullptr, ev_hyd = nullptr;  // one callback per dimension for all states (state = CMFP_ALL_STATES)
     int* d_err = nullptr;
+    int* d_flag = nullptr;      // result word of one-off device checks
     double* d_dtbuf = nullptr;  // cmfp_advance_steps: device-resident dt + dt log
     int d_dtcap = 0;
     cmfp_ell::Work ell;  // divergence projection scratch (cmfp_elliptic_project)
@@ -591,6 +595,19 @@ int advance_strang(cmfp_context* c, double dt) {
 // fused kernels cover (caller then takes the staged path), <0 on error.
 int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) {
     if (c->params.time_integrator != CMFP_TI_STRANG) return 0;
+    if (!reserve_only)
+        for (auto& st : c->states)
+            if (st.sp.kind == CMFP_STATE_FIELD && !st.vac_known) {
+                // once per upload: are the material coefficients 1 everywhere?  (They never change: F = 0 and no
+                // source touches them.)  Then the 2-D O6 update can run on the marching vacuum kernel.
+                int h = 1;
+                HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+                c->L->field_vacuum_check(c->g, st.new_data, c->d_flag, c->stream);
+                HIPCHK(c, hipMemcpyAsync(&h, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                st.sp.vacuum = h == 0;
+                st.vac_known = true;
+            }
     int n_src = 0, src = -1, coll = -1;
     std::vector<int> seen(c->states.size(), 0);
     for (size_t a = 0; a < c->actions.size(); ++a) {
@@ -679,6 +696,12 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     for (int q : list) {  // ping-pong partners of the flux kernels
         int r;
         if ((r = dalloc(c, &c->states[q].alt, c->states[q].sp.nc * c->g.sc))) return r;
+        StateRT& sq = c->states[q];
+        if (!reserve_only && sq.sp.kind == CMFP_STATE_FIELD && sq.sp.vacuum && !sq.alt_mat) {
+            HIPCHK(c, hipMemcpyAsync(sq.alt + 8 * c->g.sc, sq.new_data + 8 * c->g.sc, sizeof(double) * 2 * c->g.sc,
+                                     hipMemcpyDeviceToDevice, c->stream));
+            sq.alt_mat = true;
+        }
     }
     if (reserve_only) return 1;  // cmfp_create: everything this kernel selection allocates now exists
     if (src >= 0) {
@@ -747,7 +770,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
             epi.a = source_args(c, SA, true);
             ok = f3d[fs] ? c->L->ctu_field3d(c->g, c->states[fs].sp, nullptr, nullptr, none, nullptr, ctu_flag[epi_q], dt, c->touches,
                                              &epi, c->stream) != 0
-                         : c->L->ctu_field_src(c->g, c->states[fs].sp, nullptr, nullptr, ctu_flag[epi_q], dt, c->touches, epi, 0,
+                         : c->L->ctu_field_src(c->g, c->states[fs].sp, nullptr, nullptr, ctu_flag[epi_q], dt, c->touches, epi, 0 | tile_flag,
                                                c->stream) != 0;
         }
         if (!ok) epi_q = -1;
@@ -787,6 +810,12 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         HIPCHK(c, hipMemsetAsync(epi.red_dt, 0xff, 256 * sizeof(unsigned long long), c->stream));  // all-ones: empty (a NaN to fmin)
         c->L->source_coef(epi.a, 0.5 * dt, epi.kf);
     }
+    // Where the marching vacuum kernel takes the field with the source epilogue it is not split into interior and
+    // frame: it runs whole after the ghost fill and after every species launch (the hydro interiors still overlap
+    // the exchange, which is what hides the halo traffic of a 2-D block)
+    const bool field_whole = overlap && epi_q >= 0 && !f3d[list[epi_q]] &&
+                             c->L->ctu_march_field(c->g, c->states[list[epi_q]].sp, nullptr, nullptr, ctu_flag[epi_q], dt, c->touches, &epi,
+                                                   0 | tile_flag, c->stream) != 0;
     const Ptr3 F1{{c->gF1[0], c->gF1[1], c->gF1[2]}}, F2{{c->gF2[0], c->gF2[1], c->gF2[2]}};
     auto slot_of = [&](const StateRT& s) { return s.sp.kind == CMFP_STATE_HYDRO ? CMFP_PROF_CTU_HYDRO : CMFP_PROF_CTU_FIELD; };
     if (overlap) {
@@ -796,10 +825,11 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
             StateRT& s = c->states[list[q]];
             // the species' interiors are complete here (the epilogue field is last in `order`): the frame launch
             // of that field on the main stream, whose tiles reach into the species' interiors, waits for this
+            if ((int)q == epi_q && field_whole) continue;
             if ((int)q == epi_q) HIPCHK(c, hipEventRecord(c->ev_hyd, c->stream2));
             ProfScope prof(c, slot_of(s), c->stream2, true);
             if ((int)q == epi_q)
-                c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, 1, c->stream2);
+                c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, 1 | tile_flag, c->stream2);
             else
                 c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], 1 | tile_flag, c->stream2);
         }
@@ -827,10 +857,12 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         StateRT& s = c->states[list[q]];
         // the frame tiles of the epilogue field read and rewrite species cells that the species' interior
         // launches (second stream) update: wait for them
-        if (overlap && (int)q == epi_q) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_hyd, 0));
-        ProfScope prof(c, slot_of(s), c->stream, !overlap);
-        if ((int)q == epi_q && !f3d[list[q]])
-            c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, overlap ? 2 : 0, c->stream);
+        if (overlap && (int)q == epi_q) HIPCHK(c, hipStreamWaitEvent(c->stream, field_whole ? c->ev_int : c->ev_hyd, 0));
+        ProfScope prof(c, slot_of(s), c->stream, !overlap || ((int)q == epi_q && field_whole));
+        if ((int)q == epi_q && field_whole)
+            c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, 0 | tile_flag, c->stream);
+        else if ((int)q == epi_q && !f3d[list[q]])
+            c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, (overlap ? 2 : 0) | tile_flag, c->stream);
         else if (tiled[list[q]])
             c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], (overlap ? 2 : 0) | tile_flag,
                             c->stream);
@@ -1040,6 +1072,7 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     }
     HIPCHK(c, hipMalloc((void**)&c->d_err, sizeof(int)));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMalloc((void**)&c->d_flag, sizeof(int)));
     HIPCHK(c, hipMalloc((void**)&c->d_red, sizeof(unsigned long long) * (2 * n_states + n_actions + 1)));
     HIPCHK(c, hipMalloc((void**)&c->d_part, sizeof(double) * (size_t)(2 * n_states + n_actions + 1) * CMFP_RED_BLOCKS));
     c->red_valid.assign(2 * n_states + n_actions + 1, 0);
@@ -1076,6 +1109,7 @@ int cmfp_destroy(cmfp_context* c) {
     }
     for (double* p : c->allocs) (void)hipFree(p);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_dtbuf) (void)hipFree(c->d_dtbuf);
     cmfp_ell::release(c->ell);
     if (c->d_red) (void)hipFree(c->d_red);
@@ -1127,6 +1161,8 @@ int cmfp_state_upload(cmfp_context* c, int s, const double* host) {
     if ((r = check_ctx(c))) return r;
     if (s < 0 || s >= (int)c->states.size() || !host) return fail(c, CMFP_ERR_INVALID, "bad state index / pointer");
     std::fill(c->red_valid.begin(), c->red_valid.end(), 0);
+    c->states[s].vac_known = c->states[s].alt_mat = false;
+    c->states[s].sp.vacuum = 0;
     return copy_state(c, c->states[s].new_data, c->states[s].sp.nc, const_cast<double*>(host), true);
 }
 int cmfp_state_download(cmfp_context* c, int s, double* host) {

@@ -1,0 +1,364 @@
+// mfp_march_field.hip — wave-marching fused corner-transport-upwind update of the Maxwell state (2-D, O6,
+// vacuum materials), optionally with the Strang source stage C as its epilogue.
+//
+// Same work as k_ctu2d<FieldF<O6>, ..., SRC> of mfp_fused.hip — HydroCTU::calc_spatial_derivative
+// (MFP_CTU_hydro.cpp:142-531) + `new += dU` (MFP_advance.cpp:220-230) for the field, then stage C
+// (MFP_advance.cpp:235-281) on the cells just updated — organised like the hydro marching kernel
+// (mfp_march.hip): one wavefront owns a strip of 64 columns and marches along y, one row per iteration, so that
+// nothing is reconstructed or solved twice and no thread idles on a tile ring:
+//
+//   iteration r:  row r + 3 (prefetched) enters the wave's window of six rows in LDS
+//                 O6 interface values of row r:  x: I(i + 1/2) from the lanes i - 2 .. i + 3 of the window row,
+//                                                y: I(r + 1/2) from the window rows r - 2 .. r + 3
+//                 (the unlimited sixth-order interface value is single valued: the high face of one cell and
+//                  the low face of the next are the same sum term by term, MFP_reconstruction.cpp:261-268,
+//                  so each is computed once; bit-identical to two evaluations)
+//                 half-step trace of row r, Riemann sweep 1: F_x(r), F_y(r)
+//                 transverse corrections: y-faces of row r with F_x(r), x-faces of row r - 1 with F_y(r - 1) - F_y(r)
+//                 domain-face BCs, Riemann sweep 2: F'_y(r), F'_x(r - 1)
+//                 divergence of row r - 1, Uout = Uin + dU, [source stage C of the species at that cell]
+//
+// The window (6 rows x 8 components x 64 lanes = 24 KB per wave) is lane-private except for the x stencil, which
+// reads the neighbouring lanes' entries of the current row; face states, fluxes and the carried rows stay in
+// registers; x-neighbour face states and fluxes travel by DPP wave shifts.  No barrier between waves (one wave per
+// workgroup).  A strip updates 56 of its 64 columns (87.5 % against 76.6 % useful threads of the 14 x 14 tiles).
+//
+// Applies where the material coefficients are mu = ep = 1 on the whole block (checked once on the device: they
+// never change, F = 0 and no source touches them): their face states are then the same two constants everywhere
+// — in STRICT the values the reference's reconstruction and trace give for a flat stencil (1 + 2^-52 before the
+// trace for O6), in FAST exactly 1 (the vacuum shortcut of the Riemann solver) — so mu and ep are neither read nor
+// rewritten: 8 components of traffic instead of 10.  Same device functions and operation order per value as the
+// staged and tiled kernels: STRICT results are bit-identical to them and to the oracle.
+#include "mfp_march.h"
+#include "mfp_source.h"
+
+namespace CMFP_NS {
+
+static constexpr int FLD_MW = 56;   // columns a strip updates: lanes 4 .. 59
+static constexpr int FLD_NR = 6;    // window rows
+static constexpr int FLD_PAD = 8;   // doubles in front of and behind the window (edge lanes' x stencil reads)
+
+// the O6 interface value between s3 and s4: recon_faces<5>'s `hi` of the cell holding s3 (= `lo` of the next)
+CMFP_DEV double o6_interface(double s1, double s2, double s3, double s4, double s5, double s6) {
+    return (37.0 / 60.0) * (s3 + s4) - (2.0 / 15.0) * (s2 + s5) + (1.0 / 60.0) * (s1 + s6);
+}
+
+template <bool HAS_BC, int SRC>
+__global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldParams P, const double* __restrict__ Uin, double* __restrict__ Uout,
+                                                      double dt, MarchBC bc, MarchSel sel, typename EpiArg<SRC>::type epi) {
+    typedef FieldF<5> Phys;
+    __shared__ double ring_[FLD_NR * 8 * 64 + 2 * FLD_PAD];
+    double* const ring = ring_ + FLD_PAD;
+    dt = launch_dt(g, dt);
+    const int lane = threadIdx.x;
+    const int per = (sel.nwaves + 7) >> 3;  // XCD-aware order: neighbouring strips on one XCD
+    const int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    double src_speed[SRC > 0 ? SRC : 1], src_dt = DBL_MAX;
+#pragma unroll
+    for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s) src_speed[s] = DBL_MIN;
+    if (w < sel.nwaves) {
+        const MarchRect R = sel.r[0];
+        const int segi = w / R.ns, strip = w - segi * R.ns;
+        const int n0 = g.n[0], n1 = g.n[1];
+        const int i = R.ilo + strip * FLD_MW - 4 + lane;  // this lane's column (>= -4)
+        const int ic = i < R.ihi + 4 ? i : R.ihi + 4;      // lanes past the stencil reach re-read the last column
+        const int ja = R.jlo + segi * sel.seg;
+        const int jb = (ja + sel.seg - 1 < R.jhi) ? ja + sel.seg - 1 : R.jhi;
+        const bool upd = lane >= 4 && lane <= 59 && i <= R.ihi;
+        const double speed = P.fastest;
+        const double hx = uni(0.5 * dt / g.dx[0]), hy = uni(0.5 * dt / g.dx[1]);
+        const double dtdx = uni(dt / g.dx[0]), dtdy = uni(dt / g.dx[1]);
+        const long col = g.at(ic, 0, 0);
+        const int row0 = ja - 4;  // the row in window slot 0
+
+        // face states of mu, ep (components 8, 9) in x and y: constants of the launch
+        double mlo[2], mhi[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#ifdef CMFP_FASTMATH
+            mlo[d] = mhi[d] = 1.0;
+#else
+            const double flat[7] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+            recon_faces<5>(flat, mlo[d], mhi[d]);
+            trace_faces(speed, d == 0 ? hx : hy, 1.0, mlo[d], mhi[d]);
+#endif
+        }
+
+        auto load_row = [&](int row, double* U) {
+            const long c = col + (long)row * g.sj;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) U[n] = Uin[c + n * g.sc];
+        };
+        auto slot_of = [&](int row) { return (row - row0) % FLD_NR; };
+        auto at = [&](int slot, int n, int l) -> double& { return ring[(slot * 8 + n) * 64 + l]; };
+
+        // prologue: rows ja - 4 .. ja + 1 into the window; I_y(ja - 3/2) from them; row ja + 2 in flight
+        double Un[8];
+        for (int s = 0; s < FLD_NR; ++s) {
+            load_row(row0 + s, Un);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) at(s, n, lane) = Un[n];
+        }
+        load_row(ja + 2, Un);
+        double Iy_p[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            Iy_p[n] = o6_interface(at(0, n, lane), at(1, n, lane), at(2, n, lane), at(3, n, lane), at(4, n, lane), at(5, n, lane));
+
+        // carried from the previous iteration (row r - 1)
+        double xlo_p[8], xhi_p[8];  // traced x-face states, not yet corrected
+        double yhiU_p[8];           // traced high y-face state (sweep 1)
+        double yhiC_p[8];           // the same, transversally corrected (sweep 2)
+        double fy_p[8], fy2_p[8];   // F_y and F'_y on the low y-face
+#pragma unroll
+        for (int n = 0; n < 8; ++n) xlo_p[n] = xhi_p[n] = yhiU_p[n] = yhiC_p[n] = fy_p[n] = fy2_p[n] = 0.0;
+        // source epilogue: the species' values of the row that is updated in the next iteration, requested one
+        // iteration ahead (at one wave per SIMD nothing else hides their latency)
+        double sp_cur[SRC > 0 ? SRC : 1][5], sp_nxt[SRC > 0 ? SRC : 1][5];
+#pragma unroll
+        for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s)
+#pragma unroll
+            for (int n = 0; n < 5; ++n) sp_cur[s][n] = sp_nxt[s][n] = 1.0;
+
+        for (int r = ja - 1; r <= jb + 1; ++r) {
+            // ---- row r + 3 enters the window (it replaces row r - 3); row r + 4 is requested
+            __syncthreads();  // every lane has finished reading the slot that is overwritten
+            {
+                const int sn = slot_of(r + 3);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) at(sn, n, lane) = Un[n];
+                const int rn = r + 4 < jb + 4 ? r + 4 : jb + 4;  // rows past the segment's stencil reach are not touched
+                load_row(rn, Un);
+                if constexpr (SRC > 0) {
+                    if (upd && r >= ja && r <= jb) source_epilogue_load<SRC>(g, epi, col + (long)r * g.sj, sp_nxt);
+                }
+            }
+            __syncthreads();
+            // The phases below are ordered so that what is carried from row r - 1 is consumed (and its registers
+            // reused) as early as possible; the scheduling fences keep the compiler from interleaving them, which
+            // would push the live state of the iteration beyond the register file.
+            const int s0 = slot_of(r - 2), s1 = slot_of(r - 1), s2 = slot_of(r), s3 = slot_of(r + 1), s4 = slot_of(r + 2),
+                      s5 = slot_of(r + 3);
+            // ---- A: y interface values, face states and half-step trace of row r
+            double ylo[10], yhi[10];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const double centre = at(s2, n, lane);
+                const double Iy = o6_interface(at(s0, n, lane), at(s1, n, lane), centre, at(s3, n, lane), at(s4, n, lane), at(s5, n, lane));
+                ylo[n] = Iy_p[n];
+                yhi[n] = Iy;
+                Iy_p[n] = Iy;
+                trace_faces(speed, hy, centre, ylo[n], yhi[n]);
+            }
+            ylo[8] = ylo[9] = mlo[1];
+            yhi[8] = yhi[9] = mhi[1];
+            if constexpr (SRC == 0) __builtin_amdgcn_sched_barrier(0);
+            // ---- B: Riemann sweep 1 on the low y-face of (i, r); C: with it, the x-face states of row r - 1 get their
+            //      transverse correction F_y(r - 1) - F_y(r) (EulerianState::correct_face_prim MFP_eulerian.cpp:1047-1188,
+            //      per cell), then domain-face BCs (update_face_prim, do_all) and Riemann sweep 2 in x for row r - 1
+            double fx2[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            {
+                double fy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (r >= ja) {
+                    double L[10];
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) L[n] = yhiU_p[n];
+                    L[8] = L[9] = mhi[1];
+                    Phys::riemann(P, 1, L, ylo, fy);
+                }
+#pragma unroll
+                for (int n = 0; n < 8; ++n) yhiU_p[n] = yhi[n];
+                if (r > ja) {
+                    double dF[8];
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) dF[n] = fy_p[n] - fy[n];
+                    Phys::correct(P, xhi_p, hy, dF);
+                    Phys::correct(P, xlo_p, hy, dF);
+                    double L[10], Rr[10];
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        L[n] = lane_left(xhi_p[n]);
+                        Rr[n] = xlo_p[n];
+                    }
+                    L[8] = L[9] = mhi[0];
+                    Rr[8] = Rr[9] = mlo[0];
+                    if (HAS_BC && bc.touch[0][0] && i == 0) {
+#pragma unroll
+                        for (int n = 0; n < 10; ++n)
+                            if (bc.rule[0][0][n]) L[n] = bc.rule[0][0][n] == FILL_ODD ? -Rr[n] : Rr[n];
+                    }
+                    if (HAS_BC && bc.touch[0][1] && i == n0) {
+#pragma unroll
+                        for (int n = 0; n < 10; ++n)
+                            if (bc.rule[0][1][n]) Rr[n] = bc.rule[0][1][n] == FILL_ODD ? -L[n] : L[n];
+                    }
+                    Phys::riemann(P, 0, L, Rr, fx2);
+                }
+#pragma unroll
+                for (int n = 0; n < 8; ++n) fy_p[n] = fy[n];
+            }
+            if constexpr (SRC == 0) __builtin_amdgcn_sched_barrier(0);
+            // ---- D: x interface values, face states, trace and Riemann sweep 1 of row r; the y-face states of row r
+            //      get their transverse correction F_x(i) - F_x(i + 1)
+            {
+                double xlo[10], xhi[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const double centre = at(s2, n, lane);
+                    const double Ix = o6_interface(at(s2, n, lane - 2), at(s2, n, lane - 1), centre, at(s2, n, lane + 1),
+                                                   at(s2, n, lane + 2), at(s2, n, lane + 3));
+                    xlo[n] = lane_left(Ix);
+                    xhi[n] = Ix;
+                    trace_faces(speed, hx, centre, xlo[n], xhi[n]);
+                }
+                xlo[8] = xlo[9] = mlo[0];
+                xhi[8] = xhi[9] = mhi[0];
+                double fx[10], L[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) L[n] = lane_left(xhi[n]);
+                L[8] = L[9] = mhi[0];
+                Phys::riemann(P, 0, L, xlo, fx);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    xlo_p[n] = xlo[n];
+                    xhi_p[n] = xhi[n];
+                }
+                double dF[8];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) dF[n] = fx[n] - lane_right(fx[n]);
+                Phys::correct(P, yhi, hx, dF);
+                Phys::correct(P, ylo, hx, dF);
+            }
+            if constexpr (SRC == 0) __builtin_amdgcn_sched_barrier(0);
+            // ---- E: domain-face BCs + Riemann sweep 2 on the low y-face of (i, r)
+            double fy2[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (r >= ja) {
+                double L[10], Rr[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    L[n] = yhiC_p[n];
+                    Rr[n] = ylo[n];
+                }
+                L[8] = L[9] = mhi[1];
+                Rr[8] = Rr[9] = mlo[1];
+                if (HAS_BC && bc.touch[1][0] && r == 0) {
+#pragma unroll
+                    for (int n = 0; n < 10; ++n)
+                        if (bc.rule[1][0][n]) L[n] = bc.rule[1][0][n] == FILL_ODD ? -Rr[n] : Rr[n];
+                }
+                if (HAS_BC && bc.touch[1][1] && r == n1) {
+#pragma unroll
+                    for (int n = 0; n < 10; ++n)
+                        if (bc.rule[1][1][n]) Rr[n] = bc.rule[1][1][n] == FILL_ODD ? -L[n] : L[n];
+                }
+                Phys::riemann(P, 1, L, Rr, fy2);
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) yhiC_p[n] = yhi[n];
+            if constexpr (SRC == 0) __builtin_amdgcn_sched_barrier(0);
+            // ---- F: divergence of row r - 1 (calc_divergence MFP_eulerian.cpp:1614-1662), new += dU, [source stage C]
+            if (r > ja) {
+                double Unew[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const double fxh = lane_right(fx2[n]);
+                    double du = 0.0;
+                    du += dtdx * (fx2[n] - fxh);
+                    du += dtdy * (fy2_p[n] - fy2[n]);
+                    Unew[n] = at(s1, n, lane) + du;
+                }
+                Unew[8] = Unew[9] = 1.0;  // mu, ep: F = 0 (MFP_field_RH.cpp:33), vacuum block
+                if (upd) {
+                    const long c = col + (long)(r - 1) * g.sj;
+                    if constexpr (SRC > 0) source_epilogue_cell_pre<SRC>(g, epi, dt, c, Unew, sp_cur, src_speed, src_dt);
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) Uout[c + n * g.sc] = Unew[n];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) fy2_p[n] = fy2[n];
+            if constexpr (SRC > 0) {
+#pragma unroll
+                for (int s = 0; s < SRC; ++s)
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) sp_cur[s][n] = sp_nxt[s][n];
+            }
+        }
+    }
+    if constexpr (SRC > 0) {
+        __syncthreads();  // the window is free
+        source_epilogue_reduce<SRC>(epi, src_speed, src_dt, ring, lane, 1, (int)(blockIdx.x & 255));
+    }
+}
+
+// one flag word: 0 if every valid cell has mu == 1 and ep == 1 (set to 1 by any cell that has not); *flag must be
+// zero before the launch
+__global__ void k_fld_vacuum(Geo g, const double* __restrict__ U, int* flag) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nn = (long)g.n[0] * g.n[1] * g.n[2];
+    if (t >= nn) return;
+    const int i = (int)(t % g.n[0]), j = (int)((t / g.n[0]) % g.n[1]), k = (int)(t / ((long)g.n[0] * g.n[1]));
+    const long c = g.at(i, j, k);
+    if (U[c + F_MU * g.sc] != 1.0 || U[c + F_EP * g.sc] != 1.0) *flag = 1;
+}
+void field_vacuum_check(const Geo& g, const double* U, int* flag, hipStream_t st) {
+    const long nn = (long)g.n[0] * g.n[1] * g.n[2];
+    hipLaunchKernelGGL(k_fld_vacuum, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, g, U, flag);
+}
+
+// wave slots of the device for this kernel: 24 KB of LDS per wave -> six waves per CU
+static int fld_wave_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        slots = 1536;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            slots = p.multiProcessorCount * 6;
+    }
+    return slots;
+}
+
+// The field update of a vacuum block by the marching kernel; epi (may be null): the explicit Strang source
+// stage C as its epilogue.  Returns 0 where it does not apply (the caller then uses the tiled kernel).
+int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
+                    const int touches[3][2], const SourceEpi* epi, int part, hipStream_t st) {
+    static const int off = std::getenv("CMFP_FIELD_MARCH") ? std::atoi(std::getenv("CMFP_FIELD_MARCH")) == 0 : 0;
+    if (off || g.dim != 2 || sp.kind != 1 || !do_ctu || sp.recon != 5 || sp.flux != 10 || !sp.vacuum || part != 0) return 0;
+    if (g.ng[0] < 4 || g.ng[1] < 4 || g.n[0] < 1 || g.n[1] < 1) return 0;
+    if (epi && (epi->a.implicit || epi->a.coll.on || epi->ns < 1 || epi->ns > 2)) return 0;
+    if (!Uin) return 1;  // coverage probe
+    MarchSel sel;
+    sel.nrect = 1;
+    MarchRect& R = sel.r[0];
+    R.ilo = 0, R.ihi = g.n[0] - 1, R.jlo = 0, R.jhi = g.n[1] - 1;
+    R.ns = (g.n[0] + FLD_MW - 1) / FLD_MW;
+    R.first = 0;
+    // segments: one resident round of waves; a segment of S rows costs S + 2 iterations and a six-row prologue
+    static const int seg_env = std::getenv("CMFP_FIELD_SEG") ? std::atoi(std::getenv("CMFP_FIELD_SEG")) : 0;
+    int seg = seg_env;
+    if (seg <= 0) {
+        const int rounds = (epi ? fld_wave_slots() * 4 / 6 : fld_wave_slots()) / R.ns;  // with the epilogue: one wave per SIMD
+        seg = rounds > 0 ? (g.n[1] + rounds - 1) / rounds : g.n[1];
+        if (seg < 24) seg = 24;
+    }
+    if (seg > g.n[1]) seg = g.n[1];
+    sel.seg = seg;
+    R.nseg = (g.n[1] + seg - 1) / seg;
+    sel.nwaves = R.ns * R.nseg;
+    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
+    const MarchBC bc = make_march_bc(sp, touches);
+    const dim3 grid(((sel.nwaves + 7) / 8) * 8), block(64);
+#define FLD(BC, NS, E) hipLaunchKernelGGL((k_fld_march<BC, NS>), grid, block, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, E)
+    if (epi && epi->ns == 2) {
+        if (has_bc) FLD(true, 2, *epi); else FLD(false, 2, *epi);
+    } else if (epi && epi->ns == 1) {
+        if (has_bc) FLD(true, 1, *epi); else FLD(false, 1, *epi);
+    } else {
+        if (has_bc) FLD(true, 0, NoEpi{}); else FLD(false, 0, NoEpi{});
+    }
+#undef FLD
+    return 1;
+}
+
+}  // namespace CMFP_NS

@@ -124,18 +124,31 @@ template <> struct EpiArg<0> { typedef NoEpi type; };
 // Stage C on one updated cell of the field's CTU kernel: Unew = the field after its CTU update (in/out),
 // the species are read from and written to their new-time arrays at offset c; the CFL quantities of what
 // was written are folded into src_speed / src_dt (k_source_rk2<REDUCE>).
+// the species' new-time values at cell c, as the epilogue reads them (a kernel may request them ahead of time)
+template <int NS> CMFP_DEV void source_epilogue_load(const Geo& g, const SourceEpi& epi, long c, double (*s0)[5]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int n = 0; n < 5; ++n) s0[s][n] = epi.a.sp_U[s][c + n * g.sc];
+}
+template <int NS>
+CMFP_DEV void source_epilogue_cell_pre(const Geo& g, const SourceEpi& epi, double dt, long c, double* Unew, const double (*s0)[5],
+                                       double* src_speed, double& src_dt);
 template <int NS>
 CMFP_DEV void source_epilogue_cell(const Geo& g, const SourceEpi& epi, double dt, long c, double* Unew, double* src_speed,
                                    double& src_dt) {
+    double s0[NS][5];
+    source_epilogue_load<NS>(g, epi, c, s0);
+    source_epilogue_cell_pre<NS>(g, epi, dt, c, Unew, s0, src_speed, src_dt);
+}
+template <int NS>
+CMFP_DEV void source_epilogue_cell_pre(const Geo& g, const SourceEpi& epi, double dt, long c, double* Unew, const double (*s0)[5],
+                                       double* src_speed, double& src_dt) {
     const SourceArgs& a = epi.a;
     const double hdt = 0.5 * dt;
     SourceCoef kf{epi.kf[0], epi.kf[1], epi.kf[2]};
     if (g.dtp) kf = source_coef(a, hdt);
-    double s0[NS][5], snew[NS][4], fnew[5];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int n = 0; n < 5; ++n) s0[s][n] = a.sp_U[s][c + n * g.sc];
+    double snew[NS][4], fnew[5];
     source_rk2_explicit_cell<NS>(a, kf, hdt, Unew, s0, fnew, snew);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {

@@ -62,6 +62,7 @@ struct StatePhys {
     ViscP visc;
     FieldParams fp;
     int bc[10][3][2];
+    int vacuum;  // field: mu == 1 and ep == 1 on every cell of the block (established on the device; they never change)
 };
 
 constexpr int CMFP_RED_BLOCKS = 2048;  // block partials per reduction word
@@ -193,6 +194,11 @@ struct Launchers {
     // the tiled 2-D field update with the explicit Strang source stage C as its epilogue (mfp_fused.hip)
     int (*ctu_field_src)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
                          const int touches[3][2], const SourceEpi& epi, int part, hipStream_t);
+    // 2-D vacuum field update by the wave-marching kernel (mfp_march_field.hip), epi may be null; 0: not covered
+    int (*ctu_march_field)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
+                           const int touches[3][2], const SourceEpi* epi, int part, hipStream_t);
+    // *flag (zero before the launch) becomes 1 if a valid cell of the field array has mu != 1 or ep != 1
+    void (*field_vacuum_check)(const Geo&, const double* U, int* flag, hipStream_t);
     // the three factors of MFP_plasma5.cpp:123-129 as the source kernels compute them on the host
     void (*source_coef)(const SourceArgs&, double dt, double out[3]);
     // source_fused on a sub-box of the valid cells, without reductions

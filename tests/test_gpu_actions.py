@@ -262,6 +262,39 @@ def test_collisions_relaxation_parity(oracle, neutral):
         m.close()
 
 
+@pytest.mark.parametrize("n", [(64, 64), (61, 37), (120, 9)])
+def test_field_materials_select_the_kernel(oracle, n):
+    """The marching vacuum kernel takes the 2-D O6 field only where mu = ep = 1 on the whole block (checked on the
+    device after every upload); with a dielectric somewhere the tiled kernel runs.  Both bit-identical to the oracle
+    (STRICT), on block sizes that are no multiple of the 56-column strips / row segments; an upload of vacuum data
+    after dielectric data switches back."""
+    def problem(dielectric):
+        cfg = problems.orszag_tang_two_fluid_2d(64)
+        cfg["n_cell"] = list(n)
+        if dielectric:
+            cfg["states"]["field"]["value"]["ep"] = lambda d: 1.0 + 0.25 * (np.sin(d["x"]) > 0.5)
+            cfg["states"]["field"]["value"]["mu"] = lambda d: 1.0 + 0.5 * (np.cos(d["y"]) > 0.3)
+        return config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    for dielectric in (True, False):
+        P = problem(dielectric)
+        ref = oracle.OracleSim(P)
+        dts_ref = ref.run(5)
+        m = _gpu(P)
+        assert m.run(5) == dts_ref and m.last_advance_path() == 1
+        for s in range(3):
+            assert np.array_equal(m.download(s), ref.get_state(s)), (dielectric, P.state_names[s])
+        if dielectric:      # the same context, re-initialised with vacuum data: the check is made again
+            Pv = problem(False)
+            for s in range(3):
+                m.upload(s, Pv.initial_data(s))
+            m.time, m.dt, m.step = 0.0, None, 0
+            rv = oracle.OracleSim(Pv)
+            assert m.run(5) == rv.run(5)
+            for s in range(3):
+                assert np.array_equal(m.download(s), rv.get_state(s)), ("re-upload", P.state_names[s])
+        m.close()
+
+
 def test_force_dt(oracle):
     """force_dt > 0 is what MFP::estTimeStep returns (MFP_timestep.cpp:8): per-step driver, device-resident
     dt loop and oracle all step with exactly force_dt; states bit-identical (hard-sphere branch)."""
