@@ -9,7 +9,8 @@
 // from plane to plane, so every direction can take its stencil from an LDS tile that contains it:
 //
 //   pass 1  k_f3d_xy<1>:  (x, y) tiles marching along z: reconstruction + half-step trace in x and y,
-//                         Riemann sweep 1 -> F1[x], F1[y] (8 components each)
+//                         Riemann sweep 1 -> F1[x], F1[y] (8 components each), stored as the difference
+//                         dF_d = F_d(c) - F_d(c + e_d) of each cell: all that the corrections use
 //           k_f3d_z<1>:   (x, z) tiles marching along y: the same in z -> F1[z]
 //   pass 2  k_f3d_xy<2>:  x and y again (linear, cheap), transverse corrections from F1
 //                         (EulerianState::correct_face_prim MFP_eulerian.cpp:1047-1188: (d1+1)%3 then
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void k_f3d_xy(Geo g, FieldParams P, const d
     const int ic = i < -g.ng[0] ? -g.ng[0] : (i > n0 + g.ng[0] - 2 ? n0 + g.ng[0] - 2 : i);  // c + sx stays inside
     const int jc = j < -g.ng[1] ? -g.ng[1] : (j > n1 + g.ng[1] - 2 ? n1 + g.ng[1] - 2 : j);
     const long col = g.at(ic, jc, 0);
-    const long sx = 1, sy = g.sj, sz = g.sk;
+    const long sz = g.sk;
 
     for (int m = ka; m <= kb; ++m) {
         const long c = col + (long)m * sz;
@@ -164,9 +165,9 @@ __global__ __launch_bounds__(256, 2) void k_f3d_xy(Geo g, FieldParams P, const d
         if (PASS == 2) {
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
-                dFx[n] = F1.p[0][c + n * g.sc] - F1.p[0][c + sx + n * g.sc];
-                dFy[n] = F1.p[1][c + n * g.sc] - F1.p[1][c + sy + n * g.sc];
-                dFz[n] = F1.p[2][c + n * g.sc] - F1.p[2][c + sz + n * g.sc];
+                dFx[n] = F1.p[0][c + n * g.sc];
+                dFy[n] = F1.p[1][c + n * g.sc];
+                dFz[n] = F1.p[2][c + n * g.sc];
             }
         }
         __syncthreads();
@@ -179,9 +180,14 @@ __global__ __launch_bounds__(256, 2) void k_f3d_xy(Geo g, FieldParams P, const d
 #pragma unroll
             for (int n = 0; n < 10; ++n) L[n] = f3_row_left(hi[n]);
             FieldF<RECON>::riemann(P, 0, L, lo, F);
-            if (inner && i >= 0 && i <= n0 && j_ok) {
+            {
+                double dF[8];  // F_x(i) - F_x(i + 1): what the transverse corrections of this cell use
 #pragma unroll
-                for (int n = 0; n < 8; ++n) F1.p[0][c + n * g.sc] = F[n];
+                for (int n = 0; n < 8; ++n) dF[n] = F[n] - f3_row_right(F[n]);
+                if (inner && i >= 0 && i < n0 && j_ok) {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) F1.p[0][c + n * g.sc] = dF[n];
+                }
             }
             // ---- y
             f3_recon_lds<RECON, NP>(Pq, pc, PX, speed, hy, lo, hi);
@@ -191,9 +197,13 @@ __global__ __launch_bounds__(256, 2) void k_f3d_xy(Geo g, FieldParams P, const d
 #pragma unroll
             for (int n = 0; n < 10; ++n) L[n] = bufR[n][ty >= 1 ? tid - BX : tid];
             FieldF<RECON>::riemann(P, 1, L, lo, F);
-            if (inner && j >= 0 && j <= n1 && i_ok) {
+            __syncthreads();  // every thread has read its neighbour's face state: the buffer takes the fluxes
 #pragma unroll
-                for (int n = 0; n < 8; ++n) F1.p[1][c + n * g.sc] = F[n];
+            for (int n = 0; n < 8; ++n) bufR[n][tid] = F[n];
+            __syncthreads();
+            if (inner && j >= 0 && j < n1 && i_ok) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) F1.p[1][c + n * g.sc] = F[n] - bufR[n][tid + BX];
             }
         } else {
             double du[8];
@@ -278,8 +288,7 @@ __global__ __launch_bounds__(256, SRC > 0 ? 2 : 3) void k_f3d_z(Geo g, FieldPara
     const int ic = i > n0 + g.ng[0] - 2 ? n0 + g.ng[0] - 2 : i;  // i >= -1; c + sx stays inside
     const int kc = k > n2 + g.ng[2] - 1 ? n2 + g.ng[2] - 1 : k;  // k >= -1
     const long base = g.at(ic, 0, kc);
-    const long sx = 1, sy = g.sj;
-    const bool face = tz >= 1 && k <= n2;
+    const long sy = g.sj;
     double src_speed[SRC > 0 ? SRC : 1], src_dt = DBL_MAX;
 #pragma unroll
     for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s) src_speed[s] = DBL_MIN;
@@ -291,8 +300,8 @@ __global__ __launch_bounds__(256, SRC > 0 ? 2 : 3) void k_f3d_z(Geo g, FieldPara
         if (PASS == 2) {
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
-                dFx[n] = F1.p[0][c + n * g.sc] - F1.p[0][c + sx + n * g.sc];
-                dFy[n] = F1.p[1][c + n * g.sc] - F1.p[1][c + sy + n * g.sc];
+                dFx[n] = F1.p[0][c + n * g.sc];
+                dFy[n] = F1.p[1][c + n * g.sc];
                 du[n] = DU[c + n * g.sc];
             }
         }
@@ -322,9 +331,13 @@ __global__ __launch_bounds__(256, SRC > 0 ? 2 : 3) void k_f3d_z(Geo g, FieldPara
         }
         FieldF<RECON>::riemann(P, 2, L, lo, F);
         if (PASS == 1) {
-            if (face && tz <= 14 && i <= n0) {
+            __syncthreads();  // every thread has read its neighbour's face state: the buffer takes the fluxes
 #pragma unroll
-                for (int n = 0; n < 8; ++n) F1.p[2][c + n * g.sc] = F[n];
+            for (int n = 0; n < 8; ++n) bufR[n][tid] = F[n];
+            __syncthreads();
+            if (tz >= 1 && tz <= 14 && k < n2 && i <= n0) {  // F_z(k) - F_z(k + 1) of cell k (k >= 0 here)
+#pragma unroll
+                for (int n = 0; n < 8; ++n) F1.p[2][c + n * g.sc] = F[n] - bufR[n][tid + BX];
             }
         } else {
             __syncthreads();  // every thread has read its neighbour's face state: the buffer takes the fluxes
