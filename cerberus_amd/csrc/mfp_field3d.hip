@@ -371,6 +371,10 @@ __global__ __launch_bounds__(256, SRC > 0 ? 2 : 3) void k_f3d_z(Geo g, FieldPara
     }
 }
 
+// defined in mfp_march_field3d.hip: pass 2 on the marching kernels (O6, vacuum block); 0 where it does not apply
+int ctu_field3d_pass2_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& dF, double* DU, double dt,
+                            const int touches[3][2], const SourceEpi* epi, hipStream_t st);
+
 // tiles of `tw` cells over `nx` cells in the first tile dimension and 14 over `ny` in the second, marching over `np`
 static SelF3 make_sel(int nx, int tw, int ny, int np, int lo) {
     SelF3 s;
@@ -415,6 +419,7 @@ static int launch_f3d(const Geo& g, const StatePhys& sp, const double* Uin, doub
     const SelF3 b = make_sel(n0 + 2, 16, n2 + 1, n1 + 2, -1);
     hipLaunchKernelGGL((k_f3d_z<RECON, 1, false>), grid(b), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, b, NoEpi{});
     // pass 2: the valid cells
+    if (RECON == 5 && ctu_field3d_pass2_march(g, sp, Uin, Uout, F1, DU, dt, touches, epi, st)) return 1;
     const SelF3 c = make_sel(n0, 14, n1, n2, 0);
     const SelF3 d = make_sel(n0, 16, n2, n1, 0);
     if (has_bc)

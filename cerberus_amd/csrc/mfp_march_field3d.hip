@@ -1,0 +1,452 @@
+// mfp_march_field3d.hip — pass 2 of the 3-D field update (mfp_field3d.hip) as two wave-marching kernels
+// (O6, vacuum materials), with the Strang source stage C as the epilogue of the second.
+//
+// Pass 1 (mfp_field3d.hip) leaves dF_d = F1_d(c) - F1_d(c + e_d) of every cell.  Pass 2 of the plane-tile
+// kernels re-read U through 22 x 22 / 22 x 16 LDS tiles with 128-byte rows (measured 21 GB per 256^3 step for
+// 8 GB needed).  Here one wavefront owns 64 columns along x and marches along the direction of its stencil
+// with a six-line window in LDS (as mfp_march_field.hip does in 2-D), so every array is read once in 512-byte
+// rows and the O6 interface values are computed once:
+//
+//   k_f3m_z   march along z at fixed (x strip, j):  z-face states of plane k, corrected with dF_x then dF_y
+//             (EulerianState::correct_face_prim MFP_eulerian.cpp:1083-1093: (d1+1)%3 then (d1+2)%3), domain-face
+//             BCs, Riemann sweep 2, G_z = dt/dz (F'_z(k) - F'_z(k+1)) -> DU
+//   k_f3m_yx  march along y at fixed (x strip, k):  y-face states (dF_z then dF_x) and x-face states (dF_y then
+//             dF_z; x stencil from the window row), sweep 2, Uout = Uin + ((0 + dt/dx dF'_x) + dt/dy dF'_y) + G_z
+//             (calc_divergence order, MFP_eulerian.cpp:1614-1662), then stage C of the species at that cell
+//
+// mu, ep are constants of the launch (see mfp_march_field.hip).  Same device functions and operation order per
+// value as the plane-tile kernels: STRICT results are bit-identical to them and to the oracle.
+#include "mfp_march.h"
+#include "mfp_source.h"
+
+namespace CMFP_NS {
+
+struct FaceBC3m {
+    int touch[3][2];
+    int rule[3][2][10];
+};
+struct SelF3m {
+    int ns;      // strips along x
+    int nline;   // lines (j for the z march, k for the y march)
+    int nseg;    // segments along the marching direction
+    int seg;     // cells per segment
+    int nwaves;
+};
+
+static constexpr int F3M_NR = 6;
+static constexpr int F3M_PAD = 8;
+
+CMFP_DEV double f3m_interface(double s1, double s2, double s3, double s4, double s5, double s6) {
+    return (37.0 / 60.0) * (s3 + s4) - (2.0 / 15.0) * (s2 + s5) + (1.0 / 60.0) * (s1 + s6);
+}
+CMFP_DEV void f3m_bc(const int* rule, bool outside_is_L, double* L, double* R) {
+#pragma unroll
+    for (int n = 0; n < 10; ++n)
+        if (rule[n]) {
+            if (outside_is_L)
+                L[n] = rule[n] == FILL_ODD ? -R[n] : R[n];
+            else
+                R[n] = rule[n] == FILL_ODD ? -L[n] : L[n];
+        }
+}
+// face states of mu, ep along a direction with half-step factor h: constants of the launch
+CMFP_DEV void f3m_material_faces(double speed, double h, double& mlo, double& mhi) {
+#ifdef CMFP_FASTMATH
+    mlo = mhi = 1.0;
+    (void)speed;
+    (void)h;
+#else
+    const double flat[7] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+    recon_faces<5>(flat, mlo, mhi);
+    trace_faces(speed, h, 1.0, mlo, mhi);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------- z direction
+template <bool HAS_BC>
+__global__ __launch_bounds__(64, 2) void k_f3m_z(Geo g, FieldParams P, const double* __restrict__ U, Ptr3 dF, double* __restrict__ DU,
+                                                  double dt, FaceBC3m bc, SelF3m sel) {
+    typedef FieldF<5> Phys;
+    __shared__ double ring_[F3M_NR * 8 * 64 + 2 * F3M_PAD];
+    double* const ring = ring_ + F3M_PAD;
+    dt = launch_dt(g, dt);
+    const int lane = threadIdx.x;
+    const int per = (sel.nwaves + 7) >> 3;
+    int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (w >= sel.nwaves) return;
+    const int strip = w % sel.ns;
+    w /= sel.ns;
+    const int j = w % sel.nline, segi = w / sel.nline;
+    const int n0 = g.n[0], n2 = g.n[2];
+    const int i = strip * 64 + lane;
+    const int ic = i < n0 ? i : n0 - 1;
+    const bool upd = i < n0;
+    const int ka = segi * sel.seg;
+    const int kb = (ka + sel.seg - 1 < n2 - 1) ? ka + sel.seg - 1 : n2 - 1;
+    const double speed = P.fastest;
+    const double hx = uni(0.5 * dt / g.dx[0]), hy = uni(0.5 * dt / g.dx[1]), hz = uni(0.5 * dt / g.dx[2]);
+    const double dtdz = uni(dt / g.dx[2]);
+    const long col = g.at(ic, j, 0);
+    const long sz = g.sk;
+    const int pl0 = ka - 4;
+    double mlo, mhi;
+    f3m_material_faces(speed, hz, mlo, mhi);
+
+    auto load_plane = [&](int k, double* V) {
+        const long c = col + (long)k * sz;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) V[n] = U[c + n * g.sc];
+    };
+    auto load_dF = [&](int k, double* a, double* b) {
+        const long c = col + (long)k * sz;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            a[n] = dF.p[0][c + n * g.sc];
+            b[n] = dF.p[1][c + n * g.sc];
+        }
+    };
+    auto slot_of = [&](int k) { return (k - pl0) % F3M_NR; };
+    auto at = [&](int slot, int n) -> double& { return ring[(slot * 8 + n) * 64 + lane]; };
+
+    double Un[8], dxn[8], dyn[8];
+    for (int s = 0; s < F3M_NR; ++s) {
+        load_plane(pl0 + s, Un);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) at(s, n) = Un[n];
+    }
+    load_plane(ka + 2, Un);
+    load_dF(ka - 1, dxn, dyn);
+    double Iz_p[8], zhiC_p[8], fz_p[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        Iz_p[n] = f3m_interface(at(0, n), at(1, n), at(2, n), at(3, n), at(4, n), at(5, n));
+        zhiC_p[n] = fz_p[n] = 0.0;
+    }
+
+    for (int k = ka - 1; k <= kb + 1; ++k) {
+        double dFx[8], dFy[8];
+        {
+            const int sn = slot_of(k + 3);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                at(sn, n) = Un[n];  // lane-private: no synchronisation needed
+                dFx[n] = dxn[n];
+                dFy[n] = dyn[n];
+            }
+            const int kn = k + 4 < kb + 4 ? k + 4 : kb + 4;
+            load_plane(kn, Un);
+            const int kd = k + 1 < kb + 1 ? k + 1 : kb + 1;
+            load_dF(kd, dxn, dyn);
+        }
+        const int s0 = slot_of(k - 2), s1 = slot_of(k - 1), s2 = slot_of(k), s3 = slot_of(k + 1), s4 = slot_of(k + 2), s5 = slot_of(k + 3);
+        double zlo[10], zhi[10];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const double centre = at(s2, n);
+            const double Iz = f3m_interface(at(s0, n), at(s1, n), centre, at(s3, n), at(s4, n), at(s5, n));
+            zlo[n] = Iz_p[n];
+            zhi[n] = Iz;
+            Iz_p[n] = Iz;
+            trace_faces(speed, hz, centre, zlo[n], zhi[n]);
+            // z faces: corrected with dF_x then dF_y
+            zhi[n] += hx * dFx[n];
+            zlo[n] += hx * dFx[n];
+            zhi[n] += hy * dFy[n];
+            zlo[n] += hy * dFy[n];
+        }
+        zlo[8] = zlo[9] = mlo;
+        zhi[8] = zhi[9] = mhi;
+        double fz[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (k >= ka) {
+            double L[10];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) L[n] = zhiC_p[n];
+            L[8] = L[9] = mhi;
+            if (HAS_BC && bc.touch[2][0] && k == 0) f3m_bc(bc.rule[2][0], true, L, zlo);
+            if (HAS_BC && bc.touch[2][1] && k == n2) f3m_bc(bc.rule[2][1], false, L, zlo);
+            Phys::riemann(P, 2, L, zlo, fz);
+        }
+        if (k > ka && upd) {
+            const long c = col + (long)(k - 1) * sz;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) DU[c + n * g.sc] = dtdz * (fz_p[n] - fz[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            zhiC_p[n] = zhi[n];
+            fz_p[n] = fz[n];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ y and x directions
+template <bool HAS_BC, int SRC>
+__global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const double* __restrict__ Uin, double* __restrict__ Uout, Ptr3 dF,
+                                                   const double* __restrict__ DU, double dt, FaceBC3m bc, SelF3m sel,
+                                                   typename EpiArg<SRC>::type epi) {
+    typedef FieldF<5> Phys;
+    __shared__ double ring_[F3M_NR * 8 * 64 + 2 * F3M_PAD];
+    double* const ring = ring_ + F3M_PAD;
+    dt = launch_dt(g, dt);
+    const int lane = threadIdx.x;
+    const int per = (sel.nwaves + 7) >> 3;
+    int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    double src_speed[SRC > 0 ? SRC : 1], src_dt = DBL_MAX;
+#pragma unroll
+    for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s) src_speed[s] = DBL_MIN;
+    if (w < sel.nwaves) {
+        const int strip = w % sel.ns;
+        w /= sel.ns;
+        const int k = w % sel.nline, segi = w / sel.nline;
+        const int n0 = g.n[0], n1 = g.n[1];
+        const int i = strip * 56 - 4 + lane;
+        const int ic = i < n0 + 3 ? i : n0 + 3;
+        const bool upd = lane >= 4 && lane <= 59 && i < n0;
+        const int ja = segi * sel.seg;
+        const int jb = (ja + sel.seg - 1 < n1 - 1) ? ja + sel.seg - 1 : n1 - 1;
+        const double speed = P.fastest;
+        const double hx = uni(0.5 * dt / g.dx[0]), hy = uni(0.5 * dt / g.dx[1]), hz = uni(0.5 * dt / g.dx[2]);
+        const double dtdx = uni(dt / g.dx[0]), dtdy = uni(dt / g.dx[1]);
+        const long col = g.at(ic, 0, k);
+        const long sy = g.sj;
+        const int row0 = ja - 4;
+        double mlo[2], mhi[2];
+        f3m_material_faces(speed, hx, mlo[0], mhi[0]);
+        f3m_material_faces(speed, hy, mlo[1], mhi[1]);
+
+        auto load_row = [&](int row, double* V) {
+            const long c = col + (long)row * sy;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) V[n] = Uin[c + n * g.sc];
+        };
+        auto load_dF = [&](int row, double* a, double* b, double* cz) {
+            const long c = col + (long)row * sy;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                a[n] = dF.p[0][c + n * g.sc];
+                b[n] = dF.p[1][c + n * g.sc];
+                cz[n] = dF.p[2][c + n * g.sc];
+            }
+        };
+        auto slot_of = [&](int row) { return (row - row0) % F3M_NR; };
+        auto at = [&](int slot, int n, int l) -> double& { return ring[(slot * 8 + n) * 64 + l]; };
+
+        double Un[8], dxn[8], dyn[8], dzn[8], gzn[8];
+        for (int s = 0; s < F3M_NR; ++s) {
+            load_row(row0 + s, Un);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) at(s, n, lane) = Un[n];
+        }
+        load_row(ja + 2, Un);
+        load_dF(ja - 1, dxn, dyn, dzn);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) gzn[n] = 0.0;
+        double Iy_p[8], yhiC_p[8], fy_p[8], X_p[8], gz[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            Iy_p[n] = f3m_interface(at(0, n, lane), at(1, n, lane), at(2, n, lane), at(3, n, lane), at(4, n, lane), at(5, n, lane));
+            yhiC_p[n] = fy_p[n] = X_p[n] = gz[n] = 0.0;
+        }
+        double sp_cur[SRC > 0 ? SRC : 1][5], sp_nxt[SRC > 0 ? SRC : 1][5];
+#pragma unroll
+        for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s)
+#pragma unroll
+            for (int n = 0; n < 5; ++n) sp_cur[s][n] = sp_nxt[s][n] = 1.0;
+
+        for (int r = ja - 1; r <= jb + 1; ++r) {
+            double dFx[8], dFy[8], dFz[8];
+            __syncthreads();  // every lane has finished reading the slot that is overwritten
+            {
+                const int sn = slot_of(r + 3);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    at(sn, n, lane) = Un[n];
+                    dFx[n] = dxn[n];
+                    dFy[n] = dyn[n];
+                    dFz[n] = dzn[n];
+                    gz[n] = gzn[n];  // G_z of row r - 1 (requested in the previous iteration)
+                }
+                const int rn = r + 4 < jb + 4 ? r + 4 : jb + 4;
+                load_row(rn, Un);
+                const int rd = r + 1 < jb + 1 ? r + 1 : jb + 1;
+                load_dF(rd, dxn, dyn, dzn);
+                if (upd && r >= ja && r <= jb) {
+                    const long c = col + (long)r * sy;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) gzn[n] = DU[c + n * g.sc];
+                    if constexpr (SRC > 0) source_epilogue_load<SRC>(g, epi, c, sp_nxt);
+                }
+            }
+            __syncthreads();
+            const int s0 = slot_of(r - 2), s1 = slot_of(r - 1), s2 = slot_of(r), s3 = slot_of(r + 1), s4 = slot_of(r + 2), s5 = slot_of(r + 3);
+            // ---- y faces of row r: trace, corrected with dF_z then dF_x; BCs; sweep 2 on the low y-face
+            double fy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            {
+                double ylo[10], yhi[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const double centre = at(s2, n, lane);
+                    const double Iy = f3m_interface(at(s0, n, lane), at(s1, n, lane), centre, at(s3, n, lane), at(s4, n, lane), at(s5, n, lane));
+                    ylo[n] = Iy_p[n];
+                    yhi[n] = Iy;
+                    Iy_p[n] = Iy;
+                    trace_faces(speed, hy, centre, ylo[n], yhi[n]);
+                    yhi[n] += hz * dFz[n];
+                    ylo[n] += hz * dFz[n];
+                    yhi[n] += hx * dFx[n];
+                    ylo[n] += hx * dFx[n];
+                }
+                ylo[8] = ylo[9] = mlo[1];
+                yhi[8] = yhi[9] = mhi[1];
+                if (r >= ja) {
+                    double L[10];
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) L[n] = yhiC_p[n];
+                    L[8] = L[9] = mhi[1];
+                    if (HAS_BC && bc.touch[1][0] && r == 0) f3m_bc(bc.rule[1][0], true, L, ylo);
+                    if (HAS_BC && bc.touch[1][1] && r == n1) f3m_bc(bc.rule[1][1], false, L, ylo);
+                    Phys::riemann(P, 1, L, ylo, fy);
+                }
+#pragma unroll
+                for (int n = 0; n < 8; ++n) yhiC_p[n] = yhi[n];
+            }
+            // ---- divergence of row r - 1 and update (its x part was left by the previous iteration)
+            if (r > ja) {
+                double Unew[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    double du = X_p[n];                    // 0 + dt/dx (F'_x - F'_x+)
+                    du += dtdy * (fy_p[n] - fy[n]);
+                    du += gz[n];                           // + dt/dz (F'_z - F'_z+)
+                    Unew[n] = at(s1, n, lane) + du;
+                }
+                Unew[8] = Unew[9] = 1.0;
+                if (upd) {
+                    const long c = col + (long)(r - 1) * sy;
+                    if constexpr (SRC > 0) source_epilogue_cell_pre<SRC>(g, epi, dt, c, Unew, sp_cur, src_speed, src_dt);
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) Uout[c + n * g.sc] = Unew[n];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) fy_p[n] = fy[n];
+            // ---- x faces of row r: trace, corrected with dF_y then dF_z; BCs; sweep 2; x part of the divergence
+            {
+                double xlo[10], xhi[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const double centre = at(s2, n, lane);
+                    const double Ix = f3m_interface(at(s2, n, lane - 2), at(s2, n, lane - 1), centre, at(s2, n, lane + 1), at(s2, n, lane + 2),
+                                                    at(s2, n, lane + 3));
+                    xlo[n] = lane_left(Ix);
+                    xhi[n] = Ix;
+                    trace_faces(speed, hx, centre, xlo[n], xhi[n]);
+                    xhi[n] += hy * dFy[n];
+                    xlo[n] += hy * dFy[n];
+                    xhi[n] += hz * dFz[n];
+                    xlo[n] += hz * dFz[n];
+                }
+                xlo[8] = xlo[9] = mlo[0];
+                xhi[8] = xhi[9] = mhi[0];
+                double L[10], fx[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) L[n] = lane_left(xhi[n]);
+                L[8] = L[9] = mhi[0];
+                if (HAS_BC && bc.touch[0][0] && i == 0) f3m_bc(bc.rule[0][0], true, L, xlo);
+                if (HAS_BC && bc.touch[0][1] && i == n0) f3m_bc(bc.rule[0][1], false, L, xlo);
+                Phys::riemann(P, 0, L, xlo, fx);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    double du = 0.0;
+                    du += dtdx * (fx[n] - lane_right(fx[n]));
+                    X_p[n] = du;
+                }
+            }
+            if constexpr (SRC > 0) {
+#pragma unroll
+                for (int s = 0; s < SRC; ++s)
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) sp_cur[s][n] = sp_nxt[s][n];
+            }
+        }
+    }
+    if constexpr (SRC > 0) {
+        __syncthreads();
+        source_epilogue_reduce<SRC>(epi, src_speed, src_dt, ring, lane, 1, (int)(blockIdx.x & 255));
+    }
+}
+
+static int f3m_slots(int per_cu) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+    }
+    return cus * per_cu;
+}
+// segments along the marching direction: the count that minimises (rounds of resident waves) x (iterations per wave)
+static SelF3m f3m_select(int ns, int nline, int nmarch, int slots) {
+    SelF3m s;
+    s.ns = ns;
+    s.nline = nline;
+    long best = -1;
+    int best_n = 1;
+    for (int nseg = 1; nseg <= 16 && nseg <= nmarch; ++nseg) {
+        const int seg = (nmarch + nseg - 1) / nseg;
+        if (seg < 16 && nseg > 1) break;
+        const long waves = (long)ns * nline * ((nmarch + seg - 1) / seg);
+        const long cost = ((waves + slots - 1) / slots) * (long)(seg + 8);
+        if (best < 0 || cost < best) {
+            best = cost;
+            best_n = nseg;
+        }
+    }
+    s.seg = (nmarch + best_n - 1) / best_n;
+    s.nseg = (nmarch + s.seg - 1) / s.seg;
+    s.nwaves = ns * nline * s.nseg;
+    return s;
+}
+
+// Pass 2 of the 3-D field update on the marching kernels.  dF: the cell flux differences pass 1 left; DU: scratch
+// (8 planes) for G_z.  Returns 0 where it does not apply (the caller then runs the plane-tile pass 2).
+int ctu_field3d_pass2_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& dF, double* DU, double dt,
+                            const int touches[3][2], const SourceEpi* epi, hipStream_t st) {
+    static const int off = std::getenv("CMFP_FIELD_MARCH") ? std::atoi(std::getenv("CMFP_FIELD_MARCH")) == 0 : 0;
+    if (off || g.dim != 3 || sp.kind != 1 || sp.recon != 5 || sp.flux != 10 || !sp.vacuum) return 0;
+    if (g.ng[0] < 4 || g.ng[1] < 4 || g.ng[2] < 4) return 0;
+    if (epi && (epi->a.implicit || epi->a.coll.on || epi->ns < 1 || epi->ns > 2)) return 0;
+    FaceBC3m bc;
+    bool has_bc = false;
+    for (int d = 0; d < 3; ++d)
+        for (int s = 0; s < 2; ++s) {
+            bc.touch[d][s] = touches[d][s];
+            has_bc = has_bc || touches[d][s];
+            for (int n = 0; n < 10; ++n) {
+                const int code = sp.bc[n][d][s];  // MFP_eulerian.cpp:796-835
+                bc.rule[d][s][n] = (code == 2 || code == 4 || code == 1) ? FILL_EVEN : (code == -1 ? FILL_ODD : FILL_SKIP);
+            }
+        }
+    const dim3 block(64);
+    const SelF3m a = f3m_select((g.n[0] + 63) / 64, g.n[1], g.n[2], f3m_slots(6));
+    const dim3 ga(((a.nwaves + 7) / 8) * 8);
+    if (has_bc)
+        hipLaunchKernelGGL((k_f3m_z<true>), ga, block, 0, st, g, sp.fp, Uin, dF, DU, dt, bc, a);
+    else
+        hipLaunchKernelGGL((k_f3m_z<false>), ga, block, 0, st, g, sp.fp, Uin, dF, DU, dt, bc, a);
+    const SelF3m b = f3m_select((g.n[0] + 55) / 56, g.n[2], g.n[1], f3m_slots(4));
+    const dim3 gb(((b.nwaves + 7) / 8) * 8);
+#define F3M(BC, NS, E) hipLaunchKernelGGL((k_f3m_yx<BC, NS>), gb, block, 0, st, g, sp.fp, Uin, Uout, dF, DU, dt, bc, b, E)
+    if (epi && epi->ns == 2) {
+        if (has_bc) F3M(true, 2, *epi); else F3M(false, 2, *epi);
+    } else if (epi && epi->ns == 1) {
+        if (has_bc) F3M(true, 1, *epi); else F3M(false, 1, *epi);
+    } else {
+        if (has_bc) F3M(true, 0, NoEpi{}); else F3M(false, 0, NoEpi{});
+    }
+#undef F3M
+    return 1;
+}
+
+}  // namespace CMFP_NS
