@@ -376,6 +376,230 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
     }
 }
 
+// --------------------------------------------------------------------------------------------- pass 1
+// dF_z = F1_z(k) - F1_z(k + 1) for k in [0, n2) on the columns (i, j) in [-1, n0] x [-1, n1] (the flux boxes grown by
+// one transversally, MFP_CTU_hydro.cpp:254-268): march along z at fixed (x strip, j); lane l <-> i = -1 + 64 strip + l
+__global__ __launch_bounds__(64, 2) void k_f3m_z1(Geo g, FieldParams P, const double* __restrict__ U, double* __restrict__ dFz, double dt,
+                                                   SelF3m sel) {
+    typedef FieldF<5> Phys;
+    __shared__ double ring_[F3M_NR * 8 * 64 + 2 * F3M_PAD];
+    double* const ring = ring_ + F3M_PAD;
+    dt = launch_dt(g, dt);
+    const int lane = threadIdx.x;
+    const int per = (sel.nwaves + 7) >> 3;
+    int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (w >= sel.nwaves) return;
+    const int strip = w % sel.ns;
+    w /= sel.ns;
+    const int j = w % sel.nline - 1, segi = w / sel.nline;
+    const int n0 = g.n[0], n2 = g.n[2];
+    const int i = -1 + strip * 64 + lane;
+    const int ic = i <= n0 ? i : n0;
+    const bool upd = i <= n0;
+    const int ka = segi * sel.seg;
+    const int kb = (ka + sel.seg - 1 < n2 - 1) ? ka + sel.seg - 1 : n2 - 1;
+    const double speed = P.fastest;
+    const double hz = uni(0.5 * dt / g.dx[2]);
+    const long col = g.at(ic, j, 0);
+    const long sz = g.sk;
+    const int pl0 = ka - 4;
+    double mlo, mhi;
+    f3m_material_faces(speed, hz, mlo, mhi);
+    auto load_plane = [&](int k, double* V) {
+        const long c = col + (long)k * sz;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) V[n] = U[c + n * g.sc];
+    };
+    auto slot_of = [&](int k) { return (k - pl0) % F3M_NR; };
+    auto at = [&](int slot, int n) -> double& { return ring[(slot * 8 + n) * 64 + lane]; };
+    double Un[8], Un2[8];
+    for (int s = 0; s < F3M_NR; ++s) {
+        load_plane(pl0 + s, Un);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) at(s, n) = Un[n];
+    }
+    load_plane(ka + 2, Un);
+    load_plane(ka + 3 < kb + 4 ? ka + 3 : kb + 4, Un2);  // two planes in flight: this kernel has little else to hide latency
+    double Iz_p[8], zhi_p[8], fz_p[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        Iz_p[n] = f3m_interface(at(0, n), at(1, n), at(2, n), at(3, n), at(4, n), at(5, n));
+        zhi_p[n] = fz_p[n] = 0.0;
+    }
+    for (int k = ka - 1; k <= kb + 1; ++k) {
+        {
+            const int sn = slot_of(k + 3);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                at(sn, n) = Un[n];
+                Un[n] = Un2[n];
+            }
+            const int kn = k + 5 < kb + 4 ? k + 5 : kb + 4;
+            load_plane(kn, Un2);
+        }
+        const int s0 = slot_of(k - 2), s1 = slot_of(k - 1), s2 = slot_of(k), s3 = slot_of(k + 1), s4 = slot_of(k + 2), s5 = slot_of(k + 3);
+        double zlo[10], zhi[10];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const double centre = at(s2, n);
+            const double Iz = f3m_interface(at(s0, n), at(s1, n), centre, at(s3, n), at(s4, n), at(s5, n));
+            zlo[n] = Iz_p[n];
+            zhi[n] = Iz;
+            Iz_p[n] = Iz;
+            trace_faces(speed, hz, centre, zlo[n], zhi[n]);
+        }
+        zlo[8] = zlo[9] = mlo;
+        zhi[8] = zhi[9] = mhi;
+        double fz[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (k >= ka) {
+            double L[10];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) L[n] = zhi_p[n];
+            L[8] = L[9] = mhi;
+            Phys::riemann(P, 2, L, zlo, fz);
+        }
+        if (k > ka && upd) {
+            const long c = col + (long)(k - 1) * sz;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) dFz[c + n * g.sc] = fz_p[n] - fz[n];
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            zhi_p[n] = zhi[n];
+            fz_p[n] = fz[n];
+        }
+    }
+}
+
+// dF_y (rows [0, n1), columns [-1, n0]) and dF_x (columns [0, n0), rows [-1, n1]) on the planes k in [-1, n2]:
+// march along y at fixed (x strip, k); lane l <-> i = -1 + 56 strip - 4 + l
+__global__ __launch_bounds__(64, 2) void k_f3m_yx1(Geo g, FieldParams P, const double* __restrict__ U, double* __restrict__ dFx_out,
+                                                    double* __restrict__ dFy_out, double dt, SelF3m sel) {
+    typedef FieldF<5> Phys;
+    __shared__ double ring_[F3M_NR * 8 * 64 + 2 * F3M_PAD];
+    double* const ring = ring_ + F3M_PAD;
+    dt = launch_dt(g, dt);
+    const int lane = threadIdx.x;
+    const int per = (sel.nwaves + 7) >> 3;
+    int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (w >= sel.nwaves) return;
+    const int strip = w % sel.ns;
+    w /= sel.ns;
+    const int k = w % sel.nline - 1, segi = w / sel.nline;
+    const int n0 = g.n[0], n1 = g.n[1];
+    const int i = -1 + strip * 56 - 4 + lane;
+    const int ic = i < -4 ? -4 : (i < n0 + 3 ? i : n0 + 3);
+    const bool own = lane >= 4 && lane <= 59;
+    const int ja = segi * sel.seg;
+    const int jb = (ja + sel.seg - 1 < n1 - 1) ? ja + sel.seg - 1 : n1 - 1;
+    const double speed = P.fastest;
+    const double hx = uni(0.5 * dt / g.dx[0]), hy = uni(0.5 * dt / g.dx[1]);
+    const long col = g.at(ic, 0, k);
+    const long sy = g.sj;
+    const int row0 = ja - 4;
+    double mlo[2], mhi[2];
+    f3m_material_faces(speed, hx, mlo[0], mhi[0]);
+    f3m_material_faces(speed, hy, mlo[1], mhi[1]);
+    auto load_row = [&](int row, double* V) {
+        const long c = col + (long)row * sy;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) V[n] = U[c + n * g.sc];
+    };
+    auto slot_of = [&](int row) { return (row - row0) % F3M_NR; };
+    auto at = [&](int slot, int n, int l) -> double& { return ring[(slot * 8 + n) * 64 + l]; };
+    double Un[8], Un2[8];
+    for (int s = 0; s < F3M_NR; ++s) {
+        load_row(row0 + s, Un);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) at(s, n, lane) = Un[n];
+    }
+    load_row(ja + 2, Un);
+    load_row(ja + 3 < jb + 4 ? ja + 3 : jb + 4, Un2);
+    double Iy_p[8], yhi_p[8], fy_p[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        Iy_p[n] = f3m_interface(at(0, n, lane), at(1, n, lane), at(2, n, lane), at(3, n, lane), at(4, n, lane), at(5, n, lane));
+        yhi_p[n] = fy_p[n] = 0.0;
+    }
+    for (int r = ja - 1; r <= jb + 1; ++r) {
+        __syncthreads();
+        {
+            const int sn = slot_of(r + 3);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                at(sn, n, lane) = Un[n];
+                Un[n] = Un2[n];
+            }
+            const int rn = r + 5 < jb + 4 ? r + 5 : jb + 4;
+            load_row(rn, Un2);
+        }
+        __syncthreads();
+        const int s0 = slot_of(r - 2), s1 = slot_of(r - 1), s2 = slot_of(r), s3 = slot_of(r + 1), s4 = slot_of(r + 2), s5 = slot_of(r + 3);
+        // ---- y
+        {
+            double ylo[10], yhi[10];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const double centre = at(s2, n, lane);
+                const double Iy = f3m_interface(at(s0, n, lane), at(s1, n, lane), centre, at(s3, n, lane), at(s4, n, lane), at(s5, n, lane));
+                ylo[n] = Iy_p[n];
+                yhi[n] = Iy;
+                Iy_p[n] = Iy;
+                trace_faces(speed, hy, centre, ylo[n], yhi[n]);
+            }
+            ylo[8] = ylo[9] = mlo[1];
+            yhi[8] = yhi[9] = mhi[1];
+            double fy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (r >= ja) {
+                double L[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) L[n] = yhi_p[n];
+                L[8] = L[9] = mhi[1];
+                Phys::riemann(P, 1, L, ylo, fy);
+            }
+            if (r > ja && own && i <= n0) {
+                const long c = col + (long)(r - 1) * sy;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) dFy_out[c + n * g.sc] = fy_p[n] - fy[n];
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                yhi_p[n] = yhi[n];
+                fy_p[n] = fy[n];
+            }
+        }
+        // ---- x (rows of this segment, and the ring rows -1 / n1 by the first / last segment)
+        {
+            double xlo[10], xhi[10];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const double centre = at(s2, n, lane);
+                const double Ix = f3m_interface(at(s2, n, lane - 2), at(s2, n, lane - 1), centre, at(s2, n, lane + 1), at(s2, n, lane + 2),
+                                                at(s2, n, lane + 3));
+                xlo[n] = lane_left(Ix);
+                xhi[n] = Ix;
+                trace_faces(speed, hx, centre, xlo[n], xhi[n]);
+            }
+            xlo[8] = xlo[9] = mlo[0];
+            xhi[8] = xhi[9] = mhi[0];
+            double L[10], fx[10];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) L[n] = lane_left(xhi[n]);
+            L[8] = L[9] = mhi[0];
+            Phys::riemann(P, 0, L, xlo, fx);
+            double d[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) d[n] = fx[n] - lane_right(fx[n]);
+            const bool row_mine = (r >= ja && r <= jb) || (r == -1) || (r == n1);
+            if (row_mine && own && i >= 0 && i < n0) {
+                const long c = col + (long)r * sy;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) dFx_out[c + n * g.sc] = d[n];
+            }
+        }
+    }
+}
+
 static int f3m_slots(int per_cu) {
     static int cus = 0;
     if (!cus) {
@@ -407,6 +631,20 @@ static SelF3m f3m_select(int ns, int nline, int nmarch, int slots) {
     s.nseg = (nmarch + s.seg - 1) / s.seg;
     s.nwaves = ns * nline * s.nseg;
     return s;
+}
+
+// Pass 1 of the 3-D field update on the marching kernels: dF[d] of every cell.  0 where it does not apply.
+int ctu_field3d_pass1_march(const Geo& g, const StatePhys& sp, const double* Uin, const Ptr3& dF, double dt, hipStream_t st) {
+    static const int off = std::getenv("CMFP_FIELD_MARCH") ? std::atoi(std::getenv("CMFP_FIELD_MARCH")) == 0 : 0;
+    static const int off1 = std::getenv("CMFP_FIELD_MARCH_P1") ? std::atoi(std::getenv("CMFP_FIELD_MARCH_P1")) == 0 : 0;
+    if (off || off1 || g.dim != 3 || sp.kind != 1 || sp.recon != 5 || sp.flux != 10 || !sp.vacuum) return 0;
+    if (g.ng[0] < 4 || g.ng[1] < 4 || g.ng[2] < 4) return 0;
+    const dim3 block(64);
+    const SelF3m a = f3m_select((g.n[0] + 2 + 63) / 64, g.n[1] + 2, g.n[2], f3m_slots(6));
+    hipLaunchKernelGGL(k_f3m_z1, dim3(((a.nwaves + 7) / 8) * 8), block, 0, st, g, sp.fp, Uin, dF.p[2], dt, a);
+    const SelF3m b = f3m_select((g.n[0] + 2 + 55) / 56, g.n[2] + 2, g.n[1], f3m_slots(6));
+    hipLaunchKernelGGL(k_f3m_yx1, dim3(((b.nwaves + 7) / 8) * 8), block, 0, st, g, sp.fp, Uin, dF.p[0], dF.p[1], dt, b);
+    return 1;
 }
 
 // Pass 2 of the 3-D field update on the marching kernels.  dF: the cell flux differences pass 1 left; DU: scratch
