@@ -371,11 +371,9 @@ __global__ __launch_bounds__(256, SRC > 0 ? 2 : 3) void k_f3d_z(Geo g, FieldPara
     }
 }
 
-// defined in mfp_march_field3d.hip: pass 2 on the marching kernels (O6, vacuum block); 0 where it does not apply
-int ctu_field3d_pass2_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& dF, double* DU, double dt,
-                            const int touches[3][2], const SourceEpi* epi, hipStream_t st);
-
-int ctu_field3d_pass1_march(const Geo& g, const StatePhys& sp, const double* Uin, const Ptr3& dF, double dt, hipStream_t st);
+// defined in mfp_march_field3d.hip: both passes on the marching kernels (O6, vacuum block); 0 where it does not apply
+int ctu_field3d_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& dF, double* DU, double dt,
+                      const int touches[3][2], const SourceEpi* epi, hipStream_t st);
 
 // tiles of `tw` cells over `nx` cells in the first tile dimension and 14 over `ny` in the second, marching over `np`
 static SelF3 make_sel(int nx, int tw, int ny, int np, int lo) {
@@ -416,14 +414,12 @@ static int launch_f3d(const Geo& g, const StatePhys& sp, const double* Uin, doub
     auto grid = [](const SelF3& s) { return dim3(((s.n + 7) / 8) * 8); };
     const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
     // pass 1: cells [-1, n] in every dimension (z faces: 0 .. n2)
-    if (!(RECON == 5 && ctu_field3d_pass1_march(g, sp, Uin, F1, dt, st))) {
-        const SelF3 a = make_sel(n0 + 2, 14, n1 + 2, n2 + 2, -1);
-        hipLaunchKernelGGL((k_f3d_xy<RECON, 1, false>), grid(a), block, 0, st, g, sp.fp, Uin, F1, DU, dt, bc, a);
-        const SelF3 b = make_sel(n0 + 2, 16, n2 + 1, n1 + 2, -1);
-        hipLaunchKernelGGL((k_f3d_z<RECON, 1, false>), grid(b), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, b, NoEpi{});
-    }
+    if (RECON == 5 && ctu_field3d_march(g, sp, Uin, Uout, F1, DU, dt, touches, epi, st)) return 1;
+    const SelF3 a = make_sel(n0 + 2, 14, n1 + 2, n2 + 2, -1);
+    hipLaunchKernelGGL((k_f3d_xy<RECON, 1, false>), grid(a), block, 0, st, g, sp.fp, Uin, F1, DU, dt, bc, a);
+    const SelF3 b = make_sel(n0 + 2, 16, n2 + 1, n1 + 2, -1);
+    hipLaunchKernelGGL((k_f3d_z<RECON, 1, false>), grid(b), block, 0, st, g, sp.fp, Uin, Uout, F1, DU, dt, bc, b, NoEpi{});
     // pass 2: the valid cells
-    if (RECON == 5 && ctu_field3d_pass2_march(g, sp, Uin, Uout, F1, DU, dt, touches, epi, st)) return 1;
     const SelF3 c = make_sel(n0, 14, n1, n2, 0);
     const SelF3 d = make_sel(n0, 16, n2, n1, 0);
     if (has_bc)

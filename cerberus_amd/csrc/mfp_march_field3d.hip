@@ -78,14 +78,16 @@ __global__ __launch_bounds__(64, 2) void k_f3m_z(Geo g, FieldParams P, const dou
     w /= sel.ns;
     const int j = w % sel.nline, segi = w / sel.nline;
     const int n0 = g.n[0], n2 = g.n[2];
-    const int i = strip * 64 + lane;
-    const int ic = i < n0 ? i : n0 - 1;
-    const bool upd = i < n0;
+    const int i = strip * 56 - 4 + lane;  // dF_x of the cell comes from the x stencil of the window's centre line
+    const int ic = i < n0 + 3 ? i : n0 + 3;
+    const bool upd = lane >= 4 && lane <= 59 && i < n0;
     const int ka = segi * sel.seg;
     const int kb = (ka + sel.seg - 1 < n2 - 1) ? ka + sel.seg - 1 : n2 - 1;
     const double speed = P.fastest;
     const double hx = uni(0.5 * dt / g.dx[0]), hy = uni(0.5 * dt / g.dx[1]), hz = uni(0.5 * dt / g.dx[2]);
     const double dtdz = uni(dt / g.dx[2]);
+    double mxlo, mxhi;
+    f3m_material_faces(speed, hx, mxlo, mxhi);
     const long col = g.at(ic, j, 0);
     const long sz = g.sk;
     const int pl0 = ka - 4;
@@ -97,25 +99,23 @@ __global__ __launch_bounds__(64, 2) void k_f3m_z(Geo g, FieldParams P, const dou
 #pragma unroll
         for (int n = 0; n < 8; ++n) V[n] = U[c + n * g.sc];
     };
-    auto load_dF = [&](int k, double* a, double* b) {
+    auto load_dF = [&](int k, double* b) {
         const long c = col + (long)k * sz;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            a[n] = dF.p[0][c + n * g.sc];
-            b[n] = dF.p[1][c + n * g.sc];
-        }
+        for (int n = 0; n < 8; ++n) b[n] = dF.p[1][c + n * g.sc];
     };
     auto slot_of = [&](int k) { return (k - pl0) % F3M_NR; };
     auto at = [&](int slot, int n) -> double& { return ring[(slot * 8 + n) * 64 + lane]; };
+    auto atl = [&](int slot, int n, int l) -> double& { return ring[(slot * 8 + n) * 64 + l]; };
 
-    double Un[8], dxn[8], dyn[8];
+    double Un[8], dyn[8];
     for (int s = 0; s < F3M_NR; ++s) {
         load_plane(pl0 + s, Un);
 #pragma unroll
         for (int n = 0; n < 8; ++n) at(s, n) = Un[n];
     }
     load_plane(ka + 2, Un);
-    load_dF(ka - 1, dxn, dyn);
+    load_dF(ka - 1, dyn);
     double Iz_p[8], zhiC_p[8], fz_p[8];
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
@@ -125,20 +125,43 @@ __global__ __launch_bounds__(64, 2) void k_f3m_z(Geo g, FieldParams P, const dou
 
     for (int k = ka - 1; k <= kb + 1; ++k) {
         double dFx[8], dFy[8];
+        __syncthreads();  // every lane has finished reading the slot that is overwritten
         {
             const int sn = slot_of(k + 3);
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
-                at(sn, n) = Un[n];  // lane-private: no synchronisation needed
-                dFx[n] = dxn[n];
+                at(sn, n) = Un[n];
                 dFy[n] = dyn[n];
             }
             const int kn = k + 4 < kb + 4 ? k + 4 : kb + 4;
             load_plane(kn, Un);
             const int kd = k + 1 < kb + 1 ? k + 1 : kb + 1;
-            load_dF(kd, dxn, dyn);
+            load_dF(kd, dyn);
         }
+        __syncthreads();
         const int s0 = slot_of(k - 2), s1 = slot_of(k - 1), s2 = slot_of(k), s3 = slot_of(k + 1), s4 = slot_of(k + 2), s5 = slot_of(k + 3);
+        {
+            // dF_x of this cell: sweep-1 x fluxes of the line (j, k), recomputed from the window's centre line
+            // (the same traced face states pass 1 would have used; nothing is stored for x)
+            double xlo[10], xhi[10], L[10], fx[10];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const double centre = at(s2, n);
+                const double Ix = f3m_interface(atl(s2, n, lane - 2), atl(s2, n, lane - 1), centre, atl(s2, n, lane + 1), atl(s2, n, lane + 2),
+                                                atl(s2, n, lane + 3));
+                xlo[n] = lane_left(Ix);
+                xhi[n] = Ix;
+                trace_faces(speed, hx, centre, xlo[n], xhi[n]);
+            }
+            xlo[8] = xlo[9] = mxlo;
+            xhi[8] = xhi[9] = mxhi;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) L[n] = lane_left(xhi[n]);
+            L[8] = L[9] = mxhi;
+            Phys::riemann(P, 0, L, xlo, fx);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) dFx[n] = fx[n] - lane_right(fx[n]);
+        }
         double zlo[10], zhi[10];
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
@@ -219,11 +242,10 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
 #pragma unroll
             for (int n = 0; n < 8; ++n) V[n] = Uin[c + n * g.sc];
         };
-        auto load_dF = [&](int row, double* a, double* b, double* cz) {
+        auto load_dF = [&](int row, double* b, double* cz) {
             const long c = col + (long)row * sy;
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
-                a[n] = dF.p[0][c + n * g.sc];
                 b[n] = dF.p[1][c + n * g.sc];
                 cz[n] = dF.p[2][c + n * g.sc];
             }
@@ -231,14 +253,14 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
         auto slot_of = [&](int row) { return (row - row0) % F3M_NR; };
         auto at = [&](int slot, int n, int l) -> double& { return ring[(slot * 8 + n) * 64 + l]; };
 
-        double Un[8], dxn[8], dyn[8], dzn[8], gzn[8];
+        double Un[8], dyn[8], dzn[8], gzn[8];
         for (int s = 0; s < F3M_NR; ++s) {
             load_row(row0 + s, Un);
 #pragma unroll
             for (int n = 0; n < 8; ++n) at(s, n, lane) = Un[n];
         }
         load_row(ja + 2, Un);
-        load_dF(ja - 1, dxn, dyn, dzn);
+        load_dF(ja - 1, dyn, dzn);
 #pragma unroll
         for (int n = 0; n < 8; ++n) gzn[n] = 0.0;
         double Iy_p[8], yhiC_p[8], fy_p[8], X_p[8], gz[8];
@@ -261,7 +283,6 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
 #pragma unroll
                 for (int n = 0; n < 8; ++n) {
                     at(sn, n, lane) = Un[n];
-                    dFx[n] = dxn[n];
                     dFy[n] = dyn[n];
                     dFz[n] = dzn[n];
                     gz[n] = gzn[n];  // G_z of row r - 1 (requested in the previous iteration)
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
                 const int rn = r + 4 < jb + 4 ? r + 4 : jb + 4;
                 load_row(rn, Un);
                 const int rd = r + 1 < jb + 1 ? r + 1 : jb + 1;
-                load_dF(rd, dxn, dyn, dzn);
+                load_dF(rd, dyn, dzn);
                 if (upd && r >= ja && r <= jb) {
                     const long c = col + (long)r * sy;
 #pragma unroll
@@ -279,6 +300,28 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
             }
             __syncthreads();
             const int s0 = slot_of(r - 2), s1 = slot_of(r - 1), s2 = slot_of(r), s3 = slot_of(r + 1), s4 = slot_of(r + 2), s5 = slot_of(r + 3);
+            // ---- x faces of row r, traced; their sweep-1 fluxes give dF_x of the cell (recomputed: nothing is stored for x)
+            double xlo[10], xhi[10];
+            {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const double centre = at(s2, n, lane);
+                    const double Ix = f3m_interface(at(s2, n, lane - 2), at(s2, n, lane - 1), centre, at(s2, n, lane + 1), at(s2, n, lane + 2),
+                                                    at(s2, n, lane + 3));
+                    xlo[n] = lane_left(Ix);
+                    xhi[n] = Ix;
+                    trace_faces(speed, hx, centre, xlo[n], xhi[n]);
+                }
+                xlo[8] = xlo[9] = mlo[0];
+                xhi[8] = xhi[9] = mhi[0];
+                double L[10], fx[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) L[n] = lane_left(xhi[n]);
+                L[8] = L[9] = mhi[0];
+                Phys::riemann(P, 0, L, xlo, fx);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) dFx[n] = fx[n] - lane_right(fx[n]);
+            }
             // ---- y faces of row r: trace, corrected with dF_z then dF_x; BCs; sweep 2 on the low y-face
             double fy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             {
@@ -330,24 +373,15 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
             }
 #pragma unroll
             for (int n = 0; n < 8; ++n) fy_p[n] = fy[n];
-            // ---- x faces of row r: trace, corrected with dF_y then dF_z; BCs; sweep 2; x part of the divergence
+            // ---- x faces of row r: corrected with dF_y then dF_z; BCs; sweep 2; x part of the divergence
             {
-                double xlo[10], xhi[10];
 #pragma unroll
                 for (int n = 0; n < 8; ++n) {
-                    const double centre = at(s2, n, lane);
-                    const double Ix = f3m_interface(at(s2, n, lane - 2), at(s2, n, lane - 1), centre, at(s2, n, lane + 1), at(s2, n, lane + 2),
-                                                    at(s2, n, lane + 3));
-                    xlo[n] = lane_left(Ix);
-                    xhi[n] = Ix;
-                    trace_faces(speed, hx, centre, xlo[n], xhi[n]);
                     xhi[n] += hy * dFy[n];
                     xlo[n] += hy * dFy[n];
                     xhi[n] += hz * dFz[n];
                     xlo[n] += hz * dFz[n];
                 }
-                xlo[8] = xlo[9] = mlo[0];
-                xhi[8] = xhi[9] = mhi[0];
                 double L[10], fx[10];
 #pragma unroll
                 for (int n = 0; n < 8; ++n) L[n] = lane_left(xhi[n]);
@@ -471,10 +505,10 @@ __global__ __launch_bounds__(64, 2) void k_f3m_z1(Geo g, FieldParams P, const do
     }
 }
 
-// dF_y (rows [0, n1), columns [-1, n0]) and dF_x (columns [0, n0), rows [-1, n1]) on the planes k in [-1, n2]:
-// march along y at fixed (x strip, k); lane l <-> i = -1 + 56 strip - 4 + l
-__global__ __launch_bounds__(64, 2) void k_f3m_yx1(Geo g, FieldParams P, const double* __restrict__ U, double* __restrict__ dFx_out,
-                                                    double* __restrict__ dFy_out, double dt, SelF3m sel) {
+// dF_y = F1_y(j) - F1_y(j + 1) for j in [0, n1) on the columns (i, k) in [-1, n0] x [-1, n2]: march along y at fixed
+// (x strip, k); lane l <-> i = -1 + 64 strip + l.  (dF_x is not stored: pass 2 recomputes it from its window.)
+__global__ __launch_bounds__(64, 2) void k_f3m_y1(Geo g, FieldParams P, const double* __restrict__ U, double* __restrict__ dFy_out, double dt,
+                                                   SelF3m sel) {
     typedef FieldF<5> Phys;
     __shared__ double ring_[F3M_NR * 8 * 64 + 2 * F3M_PAD];
     double* const ring = ring_ + F3M_PAD;
@@ -487,115 +521,80 @@ __global__ __launch_bounds__(64, 2) void k_f3m_yx1(Geo g, FieldParams P, const d
     w /= sel.ns;
     const int k = w % sel.nline - 1, segi = w / sel.nline;
     const int n0 = g.n[0], n1 = g.n[1];
-    const int i = -1 + strip * 56 - 4 + lane;
-    const int ic = i < -4 ? -4 : (i < n0 + 3 ? i : n0 + 3);
-    const bool own = lane >= 4 && lane <= 59;
+    const int i = -1 + strip * 64 + lane;
+    const int ic = i <= n0 ? i : n0;
+    const bool upd = i <= n0;
     const int ja = segi * sel.seg;
     const int jb = (ja + sel.seg - 1 < n1 - 1) ? ja + sel.seg - 1 : n1 - 1;
     const double speed = P.fastest;
-    const double hx = uni(0.5 * dt / g.dx[0]), hy = uni(0.5 * dt / g.dx[1]);
+    const double hy = uni(0.5 * dt / g.dx[1]);
     const long col = g.at(ic, 0, k);
     const long sy = g.sj;
     const int row0 = ja - 4;
-    double mlo[2], mhi[2];
-    f3m_material_faces(speed, hx, mlo[0], mhi[0]);
-    f3m_material_faces(speed, hy, mlo[1], mhi[1]);
+    double mlo, mhi;
+    f3m_material_faces(speed, hy, mlo, mhi);
     auto load_row = [&](int row, double* V) {
         const long c = col + (long)row * sy;
 #pragma unroll
         for (int n = 0; n < 8; ++n) V[n] = U[c + n * g.sc];
     };
     auto slot_of = [&](int row) { return (row - row0) % F3M_NR; };
-    auto at = [&](int slot, int n, int l) -> double& { return ring[(slot * 8 + n) * 64 + l]; };
+    auto at = [&](int slot, int n) -> double& { return ring[(slot * 8 + n) * 64 + lane]; };
     double Un[8], Un2[8];
     for (int s = 0; s < F3M_NR; ++s) {
         load_row(row0 + s, Un);
 #pragma unroll
-        for (int n = 0; n < 8; ++n) at(s, n, lane) = Un[n];
+        for (int n = 0; n < 8; ++n) at(s, n) = Un[n];
     }
     load_row(ja + 2, Un);
     load_row(ja + 3 < jb + 4 ? ja + 3 : jb + 4, Un2);
     double Iy_p[8], yhi_p[8], fy_p[8];
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
-        Iy_p[n] = f3m_interface(at(0, n, lane), at(1, n, lane), at(2, n, lane), at(3, n, lane), at(4, n, lane), at(5, n, lane));
+        Iy_p[n] = f3m_interface(at(0, n), at(1, n), at(2, n), at(3, n), at(4, n), at(5, n));
         yhi_p[n] = fy_p[n] = 0.0;
     }
     for (int r = ja - 1; r <= jb + 1; ++r) {
-        __syncthreads();
         {
             const int sn = slot_of(r + 3);
 #pragma unroll
             for (int n = 0; n < 8; ++n) {
-                at(sn, n, lane) = Un[n];
+                at(sn, n) = Un[n];  // lane-private window: no synchronisation needed
                 Un[n] = Un2[n];
             }
             const int rn = r + 5 < jb + 4 ? r + 5 : jb + 4;
             load_row(rn, Un2);
         }
-        __syncthreads();
         const int s0 = slot_of(r - 2), s1 = slot_of(r - 1), s2 = slot_of(r), s3 = slot_of(r + 1), s4 = slot_of(r + 2), s5 = slot_of(r + 3);
-        // ---- y
-        {
-            double ylo[10], yhi[10];
+        double ylo[10], yhi[10];
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                const double centre = at(s2, n, lane);
-                const double Iy = f3m_interface(at(s0, n, lane), at(s1, n, lane), centre, at(s3, n, lane), at(s4, n, lane), at(s5, n, lane));
-                ylo[n] = Iy_p[n];
-                yhi[n] = Iy;
-                Iy_p[n] = Iy;
-                trace_faces(speed, hy, centre, ylo[n], yhi[n]);
-            }
-            ylo[8] = ylo[9] = mlo[1];
-            yhi[8] = yhi[9] = mhi[1];
-            double fy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (r >= ja) {
-                double L[10];
-#pragma unroll
-                for (int n = 0; n < 8; ++n) L[n] = yhi_p[n];
-                L[8] = L[9] = mhi[1];
-                Phys::riemann(P, 1, L, ylo, fy);
-            }
-            if (r > ja && own && i <= n0) {
-                const long c = col + (long)(r - 1) * sy;
-#pragma unroll
-                for (int n = 0; n < 8; ++n) dFy_out[c + n * g.sc] = fy_p[n] - fy[n];
-            }
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                yhi_p[n] = yhi[n];
-                fy_p[n] = fy[n];
-            }
+        for (int n = 0; n < 8; ++n) {
+            const double centre = at(s2, n);
+            const double Iy = f3m_interface(at(s0, n), at(s1, n), centre, at(s3, n), at(s4, n), at(s5, n));
+            ylo[n] = Iy_p[n];
+            yhi[n] = Iy;
+            Iy_p[n] = Iy;
+            trace_faces(speed, hy, centre, ylo[n], yhi[n]);
         }
-        // ---- x (rows of this segment, and the ring rows -1 / n1 by the first / last segment)
-        {
-            double xlo[10], xhi[10];
+        ylo[8] = ylo[9] = mlo;
+        yhi[8] = yhi[9] = mhi;
+        double fy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (r >= ja) {
+            double L[10];
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                const double centre = at(s2, n, lane);
-                const double Ix = f3m_interface(at(s2, n, lane - 2), at(s2, n, lane - 1), centre, at(s2, n, lane + 1), at(s2, n, lane + 2),
-                                                at(s2, n, lane + 3));
-                xlo[n] = lane_left(Ix);
-                xhi[n] = Ix;
-                trace_faces(speed, hx, centre, xlo[n], xhi[n]);
-            }
-            xlo[8] = xlo[9] = mlo[0];
-            xhi[8] = xhi[9] = mhi[0];
-            double L[10], fx[10];
+            for (int n = 0; n < 8; ++n) L[n] = yhi_p[n];
+            L[8] = L[9] = mhi;
+            Phys::riemann(P, 1, L, ylo, fy);
+        }
+        if (r > ja && upd) {
+            const long c = col + (long)(r - 1) * sy;
 #pragma unroll
-            for (int n = 0; n < 8; ++n) L[n] = lane_left(xhi[n]);
-            L[8] = L[9] = mhi[0];
-            Phys::riemann(P, 0, L, xlo, fx);
-            double d[8];
+            for (int n = 0; n < 8; ++n) dFy_out[c + n * g.sc] = fy_p[n] - fy[n];
+        }
 #pragma unroll
-            for (int n = 0; n < 8; ++n) d[n] = fx[n] - lane_right(fx[n]);
-            const bool row_mine = (r >= ja && r <= jb) || (r == -1) || (r == n1);
-            if (row_mine && own && i >= 0 && i < n0) {
-                const long c = col + (long)r * sy;
-#pragma unroll
-                for (int n = 0; n < 8; ++n) dFx_out[c + n * g.sc] = d[n];
-            }
+        for (int n = 0; n < 8; ++n) {
+            yhi_p[n] = yhi[n];
+            fy_p[n] = fy[n];
         }
     }
 }
@@ -633,28 +632,25 @@ static SelF3m f3m_select(int ns, int nline, int nmarch, int slots) {
     return s;
 }
 
-// Pass 1 of the 3-D field update on the marching kernels: dF[d] of every cell.  0 where it does not apply.
-int ctu_field3d_pass1_march(const Geo& g, const StatePhys& sp, const double* Uin, const Ptr3& dF, double dt, hipStream_t st) {
-    static const int off = std::getenv("CMFP_FIELD_MARCH") ? std::atoi(std::getenv("CMFP_FIELD_MARCH")) == 0 : 0;
-    static const int off1 = std::getenv("CMFP_FIELD_MARCH_P1") ? std::atoi(std::getenv("CMFP_FIELD_MARCH_P1")) == 0 : 0;
-    if (off || off1 || g.dim != 3 || sp.kind != 1 || sp.recon != 5 || sp.flux != 10 || !sp.vacuum) return 0;
-    if (g.ng[0] < 4 || g.ng[1] < 4 || g.ng[2] < 4) return 0;
+// Pass 1 of the 3-D field update on the marching kernels: dF_y and dF_z of every cell (dF_x is recomputed by pass 2)
+static void f3m_pass1(const Geo& g, const StatePhys& sp, const double* Uin, const Ptr3& dF, double dt, hipStream_t st) {
     const dim3 block(64);
     const SelF3m a = f3m_select((g.n[0] + 2 + 63) / 64, g.n[1] + 2, g.n[2], f3m_slots(6));
     hipLaunchKernelGGL(k_f3m_z1, dim3(((a.nwaves + 7) / 8) * 8), block, 0, st, g, sp.fp, Uin, dF.p[2], dt, a);
-    const SelF3m b = f3m_select((g.n[0] + 2 + 55) / 56, g.n[2] + 2, g.n[1], f3m_slots(6));
-    hipLaunchKernelGGL(k_f3m_yx1, dim3(((b.nwaves + 7) / 8) * 8), block, 0, st, g, sp.fp, Uin, dF.p[0], dF.p[1], dt, b);
-    return 1;
+    const SelF3m b = f3m_select((g.n[0] + 2 + 63) / 64, g.n[2] + 2, g.n[1], f3m_slots(6));
+    hipLaunchKernelGGL(k_f3m_y1, dim3(((b.nwaves + 7) / 8) * 8), block, 0, st, g, sp.fp, Uin, dF.p[1], dt, b);
 }
 
-// Pass 2 of the 3-D field update on the marching kernels.  dF: the cell flux differences pass 1 left; DU: scratch
-// (8 planes) for G_z.  Returns 0 where it does not apply (the caller then runs the plane-tile pass 2).
-int ctu_field3d_pass2_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& dF, double* DU, double dt,
-                            const int touches[3][2], const SourceEpi* epi, hipStream_t st) {
+// The 3-D field update on the marching kernels, both passes.  dF: scratch for the cell flux differences (y and z;
+// 8 planes each), DU: scratch (8 planes) for G_z.  Returns 0 where it does not apply (the caller then runs the
+// plane-tile kernels).
+int ctu_field3d_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& dF, double* DU, double dt,
+                      const int touches[3][2], const SourceEpi* epi, hipStream_t st) {
     static const int off = std::getenv("CMFP_FIELD_MARCH") ? std::atoi(std::getenv("CMFP_FIELD_MARCH")) == 0 : 0;
     if (off || g.dim != 3 || sp.kind != 1 || sp.recon != 5 || sp.flux != 10 || !sp.vacuum) return 0;
     if (g.ng[0] < 4 || g.ng[1] < 4 || g.ng[2] < 4) return 0;
     if (epi && (epi->a.implicit || epi->a.coll.on || epi->ns < 1 || epi->ns > 2)) return 0;
+    f3m_pass1(g, sp, Uin, dF, dt, st);
     FaceBC3m bc;
     bool has_bc = false;
     for (int d = 0; d < 3; ++d)
@@ -667,7 +663,7 @@ int ctu_field3d_pass2_march(const Geo& g, const StatePhys& sp, const double* Uin
             }
         }
     const dim3 block(64);
-    const SelF3m a = f3m_select((g.n[0] + 63) / 64, g.n[1], g.n[2], f3m_slots(6));
+    const SelF3m a = f3m_select((g.n[0] + 55) / 56, g.n[1], g.n[2], f3m_slots(6));
     const dim3 ga(((a.nwaves + 7) / 8) * 8);
     if (has_bc)
         hipLaunchKernelGGL((k_f3m_z<true>), ga, block, 0, st, g, sp.fp, Uin, dF, DU, dt, bc, a);
