@@ -287,8 +287,8 @@ def main():
             per = prof[1][0] / tsteps if prof[1][0] else 1
             epilogue = prof[2][0] == tsteps
             froof = roof_of(1, 320 if epilogue else 160,
-                            "3-D field CTU update, all plane-tile launches of one step" + (" + Strang source stage C of both species" if epilogue else ""),
-                            per, [("k_f3d_xy", " 1,"), ("k_f3d_z", " 1,"), ("k_f3d_xy", " 2,"), ("k_f3d_z", " 2,")])
+                            "3-D field CTU update, the four marching launches of one step (k_f3m_y1, k_f3m_z1, k_f3m_z, k_f3m_yx)" + (" + Strang source stage C of both species" if epilogue else ""),
+                            per, [("k_f3m_y1",), ("k_f3m_z1",), ("k_f3m_z<",), ("k_f3m_yx<",)])
         else:
             hname = ("k_ctu2d<HydroF<minmod,HLLC>> (LDS-tiled fused CTU update of one hydro state)" if args.tiled_hydro
                      else "k_ctu_march<HydroF<minmod,HLLC>> (wave-marching fused CTU update of one hydro state)")
@@ -296,9 +296,9 @@ def main():
             froof = None
             if prof[1][0] == tsteps:   # one field launch per step (no interior / frame split)
                 epilogue = prof[2][0] == tsteps     # one separate source launch per step: stage C is in the field kernel
-                fname = ("k_ctu2d<FieldF<O6>,SRC=2> (LDS-tiled fused CTU update of the field state + Strang source stage C of both species)"
-                         if epilogue else "k_ctu2d<FieldF<O6>> (LDS-tiled fused CTU update of the field state)")
-                froof = roof_of(1, 320 if epilogue else 160, fname, 1, [("k_ctu2d<fast::FieldF",)])
+                fname = ("k_fld_march<SRC=2> (wave-marching fused CTU update of the vacuum field state + Strang source stage C of both species)"
+                         if epilogue else "k_fld_march (wave-marching fused CTU update of the vacuum field state)")
+                froof = roof_of(1, 320 if epilogue else 160, fname, 1, [("k_fld_march",)])
         roof, other = hroof, froof
         if froof and hroof and froof["ms_per_step"] > hroof["ms_per_step"]:
             roof, other = froof, hroof

@@ -818,10 +818,22 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
                                                    0 | tile_flag, c->stream) != 0;
     const Ptr3 F1{{c->gF1[0], c->gF1[1], c->gF1[2]}}, F2{{c->gF2[0], c->gF2[1], c->gF2[2]}};
     auto slot_of = [&](const StateRT& s) { return s.sp.kind == CMFP_STATE_HYDRO ? CMFP_PROF_CTU_HYDRO : CMFP_PROF_CTU_FIELD; };
+    // two species of the same physics share one wave-marching launch (MarchStates, mfp_march.hip)
+    auto pair_launch = [&](size_t qa, size_t qb, int part, hipStream_t st) -> bool {
+        if (tile_flag || (int)qa == epi_q || (int)qb == epi_q || !tiled[list[qa]] || !tiled[list[qb]] || ctu_flag[qa] != ctu_flag[qb])
+            return false;
+        StateRT &a = c->states[list[qa]], &b = c->states[list[qb]];
+        const StatePhys* const sp[2] = {&a.sp, &b.sp};
+        const double* const in[2] = {a.new_data, b.new_data};
+        double* const out[2] = {a.alt, b.alt};
+        unsigned long long* const red[2] = {slots[qa], slots[qb]};
+        return c->L->ctu_march2(c->g, sp, in, out, ctu_flag[qa], dt, c->touches, c->d_err, red, part, st) != 0;
+    };
     if (overlap) {
         HIPCHK(c, hipEventRecord(c->ev_src, c->stream));  // source stage A (and the slot resets) done
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_src, 0));
-        for (size_t q : order) {
+        for (size_t k = 0; k < order.size(); ++k) {
+            const size_t q = order[k];
             StateRT& s = c->states[list[q]];
             // the species' interiors are complete here (the epilogue field is last in `order`): the frame launch
             // of that field on the main stream, whose tiles reach into the species' interiors, waits for this
@@ -830,6 +842,8 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
             ProfScope prof(c, slot_of(s), c->stream2, true);
             if ((int)q == epi_q)
                 c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, 1 | tile_flag, c->stream2);
+            else if (k + 1 < order.size() && pair_launch(q, order[k + 1], 1, c->stream2))
+                ++k;
             else
                 c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], 1 | tile_flag, c->stream2);
         }
@@ -853,7 +867,8 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         HIPCHK(c, hipEventRecord(c->ev_int, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_int, 0));
     }
-    for (size_t q : order) {
+    for (size_t k = 0; k < order.size(); ++k) {
+        const size_t q = order[k];
         StateRT& s = c->states[list[q]];
         // the frame tiles of the epilogue field read and rewrite species cells that the species' interior
         // launches (second stream) update: wait for them
@@ -863,6 +878,8 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
             c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, 0 | tile_flag, c->stream);
         else if ((int)q == epi_q && !f3d[list[q]])
             c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, (overlap ? 2 : 0) | tile_flag, c->stream);
+        else if (k + 1 < order.size() && pair_launch(q, order[k + 1], overlap ? 2 : 0, c->stream))
+            ++k;
         else if (tiled[list[q]])
             c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], (overlap ? 2 : 0) | tile_flag,
                             c->stream);

@@ -91,9 +91,9 @@ static inline bool march_select(const Geo& g, int part, int ring, int mw, int mu
         add(n0 - fx, n0 - 1, fy, n1 - 1 - fy);
     }
     if (sel.nrect == 0) return false;
-    // segment length: one resident round of waves where the block is large enough for segments of
-    // >= 12 rows, else 12-row segments (measured on 1024^2 blocks: 12 rows beat 32 by 20-40 %, the three
-    // rows of pipeline start-up per segment cost less than the empty wave slots)
+    // segment length: one resident round of waves, segments of >= 6 rows (measured on 1024^2 blocks: 12 rows
+    // beat 32 by 20-40 %, on 512^2 6 beat 12 by 35 %: the three rows of pipeline start-up per segment cost
+    // less than empty wave slots)
     int strips = 0;
     for (int q = 0; q < sel.nrect; ++q) strips = strips > sel.r[q].ns ? strips : sel.r[q].ns;
     static const int seg_env = std::getenv("CMFP_MARCH_SEG") ? std::atoi(std::getenv("CMFP_MARCH_SEG")) : 0;
@@ -102,10 +102,13 @@ static inline bool march_select(const Geo& g, int part, int ring, int mw, int mu
         const int rounds = wave_slots() / (strips * mult);  // segments per strip that fit one round
         seg = rounds > 0 ? (n1 + rounds - 1) / rounds : n1;
         // three rounds of shorter segments balance the tail better where they stay long (4096^2: 48 rows
-        // against 142, hydro launch 3 % faster; 2048^2: no difference between 12 and 36)
-        const int seg3 = rounds > 0 ? (n1 + 3 * rounds - 1) / (3 * rounds) : n1;
+        // against 142, hydro launch 3 % faster; 2048^2: no difference between 12 and 36); two states in one
+        // launch keep the segments of one (4096^2: 48 rows, six rounds)
+        const int rounds1 = wave_slots() / strips;
+        const int seg3 = rounds1 > 0 ? (n1 + 3 * rounds1 - 1) / (3 * rounds1) : n1;
         if (seg3 >= 36) seg = seg3;
-        if (seg < 12) seg = 12;
+        static const int seg_min = std::getenv("CMFP_MARCH_SEG_MIN") ? std::atoi(std::getenv("CMFP_MARCH_SEG_MIN")) : 6;
+        if (seg < seg_min) seg = seg_min;
     }
     sel.seg = seg;
     sel.nwaves = 0;

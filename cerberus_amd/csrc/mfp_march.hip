@@ -20,23 +20,42 @@
 // 77 % of the 16 x 16 tile kernel (which also converts the 18 x 18 halo to primitives per tile).
 // Arithmetic per value is the same sequence of device functions as the staged and tiled kernels:
 // STRICT results are identical to them bit for bit.
+#include <cstring>
+
 #include "mfp_march.h"
 
 namespace CMFP_NS {
 static constexpr int MW = 60;  // columns a strip updates
 
+// The states one launch updates: one, or two species of the same physics (reconstruction, Riemann solver,
+// boundary rules) whose waves share the launch — on blocks of <= 1024^2 cells one state's waves leave
+// most SIMDs idle or alone, and two launches in a row cost twice the march of one.
+template <class Phys>
+struct MarchStates {
+    int n;
+    typename Phys::Params P[2];
+    const double* Uin[2];
+    double* Uout[2];
+    unsigned long long* red[2];
+};
+
 template <class Phys, bool HAS_BC, bool REDUCE>
-__global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
-                                                      double* __restrict__ Uout, double dt, MarchBC bc, int* err, MarchSel sel,
-                                                      unsigned long long* red) {
+__global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S, double dt, MarchBC bc, int* err, MarchSel sel) {
     constexpr int RECON = Phys::RECON;
     static_assert(ReconTraits<RECON>::SL == 3 && Phys::IS_HYDRO, "three-point hydro reconstructions");
     dt = launch_dt(g, dt);  // device-resident time step (cmfp_advance_steps)
     const int lane = threadIdx.x;
     // XCD-aware order (see mfp_fused.hip): neighbouring strips, which share stencil columns, run on one XCD
-    const int per = (sel.nwaves + 7) >> 3;
+    const int total = sel.nwaves * S.n;
+    const int per = (total + 7) >> 3;
     int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (w >= sel.nwaves) return;
+    if (w >= total) return;
+    const int which = w >= sel.nwaves ? 1 : 0;  // workgroup-uniform: the state this wave updates
+    w -= which * sel.nwaves;
+    const typename Phys::Params P = S.P[which];
+    const double* __restrict__ Uin = S.Uin[which];
+    double* __restrict__ Uout = S.Uout[which];
+    unsigned long long* red = S.red[which];
     MarchRect R = sel.r[0];
 #pragma unroll
     for (int t = 1; t < 4; ++t)
@@ -239,19 +258,27 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, typename Phys::Param
 }
 
 template <class Phys>
-static int launch_march(const Geo& g, const typename Phys::Params& P, const StatePhys& sp, const double* Uin, double* Uout,
-                        double dt, const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st) {
+static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2],
+                        double dt, const int touches[3][2], int* err, unsigned long long* const red[2], int part, hipStream_t st) {
     if (g.ng[0] < 2 || g.ng[1] < 2) return 0;
     const bool has_int = g.n[0] >= 5 && g.n[1] >= 5;  // cells whose stencil footprint (+-2) stays inside valid cells
-    if (!Uin) return part == 1 ? has_int : 1;
+    if (!Uin[0]) return part == 1 ? has_int : 1;
     MarchSel sel;
-    if (!march_select(g, part, 2, MW, 1, sel)) return 1;
+    if (!march_select(g, part, 2, MW, n, sel)) return 1;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
-    const MarchBC bc = make_march_bc(sp, touches);
-    const dim3 grid(((sel.nwaves + 7) / 8) * 8), block(64);
-#define CMFP_LAUNCH(BC, RED) \
-    hipLaunchKernelGGL((k_ctu_march<Phys, BC, RED>), grid, block, 0, st, g, P, Uin, Uout, dt, bc, err, sel, red)
-    if (red) {
+    const MarchBC bc = make_march_bc(*sp[0], touches);
+    MarchStates<Phys> S;
+    std::memset(&S, 0, sizeof(S));
+    S.n = n;
+    for (int k = 0; k < n; ++k) {
+        S.P[k] = sp[k]->hp;
+        S.Uin[k] = Uin[k];
+        S.Uout[k] = Uout[k];
+        S.red[k] = red[k];
+    }
+    const dim3 grid(((sel.nwaves * n + 7) / 8) * 8), block(64);
+#define CMFP_LAUNCH(BC, RED) hipLaunchKernelGGL((k_ctu_march<Phys, BC, RED>), grid, block, 0, st, g, S, dt, bc, err, sel)
+    if (red[0]) {
         if (has_bc) CMFP_LAUNCH(true, true); else CMFP_LAUNCH(false, true);
     } else {
         if (has_bc) CMFP_LAUNCH(true, false); else CMFP_LAUNCH(false, false);
@@ -266,8 +293,29 @@ static int launch_march(const Geo& g, const typename Phys::Params& P, const Stat
 int ctu_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
               const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st) {
     if (g.dim != 2 || sp.kind != 0 || !do_ctu) return 0;
+    const StatePhys* const sps[2] = {&sp, nullptr};
+    const double* const in[2] = {Uin, nullptr};
+    double* const out[2] = {Uout, nullptr};
+    unsigned long long* const reds[2] = {red, nullptr};
 #define HY(R, F) \
-    if (sp.recon == R && sp.flux == F) return launch_march<HydroF<R, F>>(g, sp.hp, sp, Uin, Uout, dt, touches, err, red, part, st);
+    if (sp.recon == R && sp.flux == F) return launch_march<HydroF<R, F>>(g, 1, sps, in, out, dt, touches, err, reds, part, st);
+    HY(1, 0) HY(1, 1) HY(1, 2) HY(2, 0) HY(2, 1) HY(2, 2) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)
+#undef HY
+    return 0;
+}
+
+// Two hydro states in one launch (see MarchStates).  Returns 0 — nothing launched — unless both are covered
+// by ctu_march with the same kernel instance and the same domain-face rules; Uin[0] == nullptr probes.
+int ctu_march2(const Geo& g, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
+               const int touches[3][2], int* err, unsigned long long* const red[2], int part, hipStream_t st) {
+    const StatePhys &a = *sp[0], &b = *sp[1];
+    if (g.dim != 2 || a.kind != 0 || b.kind != 0 || !do_ctu) return 0;
+    if (a.recon != b.recon || a.flux != b.flux || a.nc != b.nc || (red[0] == nullptr) != (red[1] == nullptr)) return 0;
+    if (std::memcmp(a.bc, b.bc, sizeof(a.bc)) != 0) return 0;
+    static const bool off = std::getenv("CMFP_MARCH_PAIR") && std::atoi(std::getenv("CMFP_MARCH_PAIR")) == 0;
+    if (off) return 0;
+#define HY(R, F) \
+    if (a.recon == R && a.flux == F) return launch_march<HydroF<R, F>>(g, 2, sp, Uin, Uout, dt, touches, err, red, part, st);
     HY(1, 0) HY(1, 1) HY(1, 2) HY(2, 0) HY(2, 1) HY(2, 2) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)
 #undef HY
     return 0;

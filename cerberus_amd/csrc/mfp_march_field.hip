@@ -340,7 +340,10 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
     if (seg <= 0) {
         const int rounds = (epi ? fld_wave_slots() * 4 / 6 : fld_wave_slots()) / R.ns;  // with the epilogue: one wave per SIMD
         seg = rounds > 0 ? (g.n[1] + rounds - 1) / rounds : g.n[1];
-        if (seg < 24) seg = 24;
+        // small blocks: short segments that put one wave on every SIMD beat long ones on a few (512^2: 6 rows
+        // against 24, launch 0.10 -> see DESIGN.md section 3); the eight rows of start-up only cost where waves queue
+        static const int seg_min = std::getenv("CMFP_FIELD_SEG_MIN") ? std::atoi(std::getenv("CMFP_FIELD_SEG_MIN")) : 6;
+        if (seg < seg_min) seg = seg_min;
     }
     if (seg > g.n[1]) seg = g.n[1];
     sel.seg = seg;

@@ -194,6 +194,9 @@ struct Launchers {
     // the tiled 2-D field update with the explicit Strang source stage C as its epilogue (mfp_fused.hip)
     int (*ctu_field_src)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
                          const int touches[3][2], const SourceEpi& epi, int part, hipStream_t);
+    // two 2-D hydro states of the same physics in one wave-marching launch (mfp_march.hip); 0: not covered, nothing launched
+    int (*ctu_march2)(const Geo&, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
+                      const int touches[3][2], int* err, unsigned long long* const red[2], int part, hipStream_t);
     // 2-D vacuum field update by the wave-marching kernel (mfp_march_field.hip), epi may be null; 0: not covered
     int (*ctu_march_field)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
                            const int touches[3][2], const SourceEpi* epi, int part, hipStream_t);
