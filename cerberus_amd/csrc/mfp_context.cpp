@@ -99,6 +99,7 @@ struct cmfp_context {
     bool no_alloc = false;  // inside cmfp_advance_steps_static: anything that would allocate fails instead
     unsigned long long* d_red = nullptr;  // one reduction word per state + per action
     double* d_part = nullptr;             // CMFP_RED_BLOCKS block partials per word
+    std::vector<char> word_clean;         // per word: its 256 atomic slots hold the identity of its fold (k_reduce_many left them so)
     std::vector<char> red_valid;          // word already holds the reduction of the current new-time data
     std::string err;
     int last_fused = 0;
@@ -778,6 +779,34 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     // Halo/compute overlap: where the block is split between ranks, the flux update of the tiles
     // whose stencils stay inside valid cells runs on a second stream while the ghost layers are
     // packed, exchanged and unpacked on the main one; the frame of boundary tiles follows the fill.
+    // The reduction words this step's kernels write with atomics: one launch at the end of the step folds them
+    // and leaves their slots reset for the next step (k_reduce_many); a word that something else has used since
+    // is reset by one launch here.
+    std::vector<int> fold_word, fold_max, fold_mode, reset_word, reset_max;
+    auto use_word = [&](int w, int is_max, int mode) {
+        if (!c->word_clean[w]) {
+            reset_word.push_back(w);
+            reset_max.push_back(is_max);
+        }
+        c->word_clean[w] = 0;  // until this step's fold has been enqueued
+        fold_word.push_back(w);
+        fold_max.push_back(is_max);
+        fold_mode.push_back(mode);
+        return reinterpret_cast<unsigned long long*>(c->d_part + (size_t)w * CMFP_RED_BLOCKS);
+    };
+    auto launch_jobs = [&](const std::vector<int>& words, const std::vector<int>& is_max, const std::vector<int>* mode) {
+        for (size_t b = 0; b < words.size(); b += RedJobs::MAX) {
+            RedJobs J;
+            std::memset(&J, 0, sizeof(J));
+            for (size_t k = b; k < words.size() && k < b + RedJobs::MAX; ++k, ++J.n) {
+                J.slots[J.n] = reinterpret_cast<unsigned long long*>(c->d_part + (size_t)words[k] * CMFP_RED_BLOCKS);
+                J.out[J.n] = c->d_red + words[k];
+                J.is_max[J.n] = is_max[k];
+                J.mode[J.n] = mode ? (*mode)[k] : 1;
+            }
+            c->L->reduce_many(J, c->stream);
+        }
+    };
     std::vector<unsigned long long*> slots(list.size(), nullptr);
     for (size_t q = 0; q < list.size(); ++q) {
         StateRT& s = c->states[list[q]];
@@ -789,10 +818,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
             for (int k = 0; k < SA.n_states - 1; ++k)
                 if (SA.states[k] == list[q]) reduce = false;
         }
-        if (reduce) {
-            slots[q] = reinterpret_cast<unsigned long long*>(c->d_part + (size_t)list[q] * CMFP_RED_BLOCKS);
-            HIPCHK(c, hipMemsetAsync(slots[q], 0, 256 * sizeof(unsigned long long), c->stream));
-        }
+        if (reduce) slots[q] = use_word(list[q], 1, 0);
     }
     std::vector<size_t> order;  // launch order: the field with the source epilogue goes last
     for (size_t q = 0; q < list.size(); ++q)
@@ -803,13 +829,12 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         const int ns = (int)c->states.size();
         for (int n = 0; n < epi.ns; ++n) {
             epi.a.sp_U[n] = c->states[SA.states[n]].alt;  // where the species' CTU kernels write
-            epi.red_speed[n] = reinterpret_cast<unsigned long long*>(c->d_part + (size_t)SA.states[n] * CMFP_RED_BLOCKS);
-            HIPCHK(c, hipMemsetAsync(epi.red_speed[n], 0, 256 * sizeof(unsigned long long), c->stream));
+            epi.red_speed[n] = use_word(SA.states[n], 1, 0);
         }
-        epi.red_dt = reinterpret_cast<unsigned long long*>(c->d_part + (size_t)(ns + src) * CMFP_RED_BLOCKS);
-        HIPCHK(c, hipMemsetAsync(epi.red_dt, 0xff, 256 * sizeof(unsigned long long), c->stream));  // all-ones: empty (a NaN to fmin)
+        epi.red_dt = use_word(ns + src, 0, epi.a.limits_dt ? 0 : 1);  // all-ones: empty (a NaN to fmin)
         c->L->source_coef(epi.a, 0.5 * dt, epi.kf);
     }
+    launch_jobs(reset_word, reset_max, nullptr);
     // Where the marching vacuum kernel takes the field with the source epilogue it is not split into interior and
     // frame: it runs whole after the ghost fill and after every species launch (the hydro interiors still overlap
     // the exchange, which is what hides the halo traffic of a 2-D block)
@@ -890,34 +915,25 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
             c->L->ctu_gather(c->g, s.sp, s.new_data, s.alt, F1, F2, ctu_flag[q], dt, c->touches, c->d_err, slots[q], c->stream);
     }
     if (overlap) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_int, 0));
-    for (size_t q = 0; q < list.size(); ++q) {
-        StateRT& s = c->states[list[q]];
-        if (slots[q]) {
-            c->L->reduce_final(reinterpret_cast<const double*>(slots[q]), 256, 1, c->d_red + list[q], c->stream);
-            c->red_valid[list[q]] = 1;
-        }
-        std::swap(s.new_data, s.alt);
+    // the CTU kernels' speed slots and, where stage C ran inside the field kernel, its slots: folded by one launch
+    launch_jobs(fold_word, fold_max, &fold_mode);
+    for (size_t k = 0; k < fold_word.size(); ++k) {
+        c->word_clean[fold_word[k]] = 1;
+        if (fold_mode[k] == 0) c->red_valid[fold_word[k]] = 1;
     }
-    if (epi_q >= 0) {
-        // stage C ran inside the field kernel: fold its reduction slots
-        const cmfp_action_desc& A = c->actions[src];
-        const int ns = (int)c->states.size();
-        for (int n = 0; n < epi.ns; ++n) {
-            c->L->reduce_final(reinterpret_cast<const double*>(epi.red_speed[n]), 256, 1, c->d_red + A.states[n], c->stream);
-            c->red_valid[A.states[n]] = 1;
-        }
-        if (epi.a.limits_dt) {
-            c->L->reduce_final(reinterpret_cast<const double*>(epi.red_dt), 256, 0, c->d_red + ns + src, c->stream);
-            c->red_valid[c->states.size() + src] = 1;
-        }
-    } else if (src >= 0) {
+    for (size_t q = 0; q < list.size(); ++q) std::swap(c->states[list[q]].new_data, c->states[list[q]].alt);
+    if (epi_q < 0 && src >= 0) {
         SourceArgs a = source_args(c, c->actions[src], true);
         if (coll >= 0) a.coll = coll_args(c, c->actions[coll]);
         ProfScope prof(c, CMFP_PROF_SOURCE);
         // last kernel of the step: it also leaves the CFL reductions of what it wrote
         c->L->source_fused(c->g, a, 0.5 * dt, 1, c->stream);
         const cmfp_action_desc& A = c->actions[src];
-        for (int n = 0; n < A.n_states - 1; ++n) c->red_valid[A.states[n]] = 1;
+        for (int n = 0; n < A.n_states - 1; ++n) {
+            c->red_valid[A.states[n]] = 1;
+            c->word_clean[A.states[n]] = 0;  // the source kernel leaves block partials in its words
+        }
+        c->word_clean[c->states.size() + src] = 0;
         if (a.limits_dt) c->red_valid[c->states.size() + src] = 1;
     }
     return any_gather ? 2 : 1;
@@ -1092,6 +1108,7 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     HIPCHK(c, hipMalloc((void**)&c->d_flag, sizeof(int)));
     HIPCHK(c, hipMalloc((void**)&c->d_red, sizeof(unsigned long long) * (2 * n_states + n_actions + 1)));
     HIPCHK(c, hipMalloc((void**)&c->d_part, sizeof(double) * (size_t)(2 * n_states + n_actions + 1) * CMFP_RED_BLOCKS));
+    c->word_clean.assign((size_t)(2 * n_states + n_actions + 1), 0);
     c->red_valid.assign(2 * n_states + n_actions + 1, 0);
     {
         // what the fused Strang step of the default kernel selection allocates (ping-pong partners, flux
@@ -1252,6 +1269,7 @@ static double as_double(unsigned long long b) {
 
 // launches the reduction for state s into word w; hydro only
 static int launch_state_dt(cmfp_context* c, int s, int w) {
+    c->word_clean[w] = 0;
     c->L->max_speed(c->g, c->states[s].sp, c->states[s].new_data, c->d_part + (size_t)w * CMFP_RED_BLOCKS, c->d_red + w,
                     c->stream);
     return CMFP_OK;
@@ -1263,6 +1281,7 @@ static bool state_viscous(const cmfp_context* c, int s) {
 static int visc_word(const cmfp_context* c, int s) { return (int)(c->states.size() + c->actions.size()) + s; }
 static int launch_visc_dt(cmfp_context* c, int s) {
     const int w = visc_word(c, s);
+    c->word_clean[w] = 0;
     c->L->visc_stability(c->g, c->states[s].sp, c->states[s].new_data, c->d_part + (size_t)w * CMFP_RED_BLOCKS, c->d_red + w,
                          c->stream);
     return CMFP_OK;
@@ -1282,6 +1301,7 @@ static double state_dt_from(const cmfp_context* c, int s, double max_speed, doub
 }
 static int launch_action_dt(cmfp_context* c, int a, int w) {
     SourceArgs sa = source_args(c, c->actions[a], true);
+    c->word_clean[w] = 0;
     c->L->plasma_dt(c->g, sa, c->d_part + (size_t)w * CMFP_RED_BLOCKS, c->d_red + w, c->stream);
     return CMFP_OK;
 }

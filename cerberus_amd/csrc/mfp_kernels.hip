@@ -633,6 +633,31 @@ __global__ void k_reduce_final(const double* __restrict__ part, int nb, int is_m
     }
 }
 
+// one workgroup per job of a RedJobs: fold the 256 atomic slots of a reduction word and reset them
+__global__ __launch_bounds__(256) void k_reduce_many(RedJobs J) {
+    const int job = blockIdx.x;
+    unsigned long long* const slots = J.slots[job];
+    const int is_max = J.is_max[job];
+    const unsigned long long identity = is_max ? 0ull : ~0ull;
+    if (J.mode[job] == 0) {
+        double v = __longlong_as_double((long long)slots[threadIdx.x]);
+        __shared__ double sh[4];
+        v = is_max ? wave_max(v) : wave_min(v);  // fmax / fmin: the all-ones NaN of an untouched slot is ignored
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) v = is_max ? fmax(v, sh[w]) : fmin(v, sh[w]);
+            // as k_reduce_final over the same slots: DBL_MIN / DBL_MAX where no lane contributed
+            v = is_max ? fmax(v, DBL_MIN) : fmin(v, DBL_MAX);
+            *J.out[job] = (unsigned long long)__double_as_longlong(v);
+        }
+    }
+    slots[threadIdx.x] = identity;
+}
+static void l_reduce_many(const RedJobs& J, hipStream_t st) {
+    if (J.n > 0) hipLaunchKernelGGL(k_reduce_many, dim3(J.n), dim3(256), 0, st, J);
+}
+
 // fused form of one Strang source stage with the RK2 inner integrator
 // (MFP_advance.cpp:146-197 / 235-281), in place on the new-time data:
 //   U1 = U0 + S(U0) ; U2 = U1 + S(U1) ; new = 0.5 U0 + 0.5 U2
@@ -940,9 +965,12 @@ __device__ __forceinline__ void fill_dim_cell(const Geo& g, const IBox& slab, lo
     int s3[3] = {c3[0], c3[1], c3[2]};
     c3[d] = idst;
     const long cd = g.at(c3[0], c3[1], c3[2]);
-    for (int m = 0; m < nc; ++m) {
-        const int r = rules.rule[m];
-        if (r == FILL_SKIP) continue;
+    // all loads first, then all stores: source and destination are the same array, so a load after a store
+    // would wait for it (ten dependent round trips to memory per thread instead of one)
+    double v[10];
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {
+        const int r = m < nc ? rules.rule[m] : FILL_SKIP;
         int isrc;
         if (r == FILL_WRAP)
             isrc = side == 0 ? n - layer : layer - 1;
@@ -951,8 +979,12 @@ __device__ __forceinline__ void fill_dim_cell(const Geo& g, const IBox& slab, lo
         else
             isrc = side == 0 ? layer - 1 : n - layer;
         s3[d] = isrc;
-        const double v = A[g.at(s3[0], s3[1], s3[2]) + m * g.sc];
-        A[cd + m * g.sc] = (r == FILL_ODD) ? -v : v;
+        v[m] = (r == FILL_SKIP) ? 0.0 : A[g.at(s3[0], s3[1], s3[2]) + m * g.sc];
+    }
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {
+        const int r = m < nc ? rules.rule[m] : FILL_SKIP;
+        if (r != FILL_SKIP) A[cd + m * g.sc] = (r == FILL_ODD) ? -v[m] : v[m];
     }
 }
 
@@ -1404,7 +1436,7 @@ const Launchers* launchers() {
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack, l_fill_multi,
                                 ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, ctu_field_src, ctu_march2, ctu_march_field, field_vacuum_check, l_source_coef, l_source_fused_box, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
-                                l_leaf_prim2cons, l_reduce_final, l_new_dt};
+                                l_leaf_prim2cons, l_reduce_final, l_reduce_many, l_new_dt};
     return &L;
 }
 

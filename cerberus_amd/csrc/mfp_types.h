@@ -66,6 +66,17 @@ struct StatePhys {
 };
 
 constexpr int CMFP_RED_BLOCKS = 2048;  // block partials per reduction word
+// The 256 atomic slots of several reduction words handled by one launch (k_reduce_many): fold the slots into
+// *out (mode 0) and leave them at the identity of the fold (0 for a maximum of positive doubles, all-ones —
+// a NaN that fmin ignores — for a minimum) for the next step's atomics; mode 1 only resets.
+struct RedJobs {
+    static constexpr int MAX = 12;
+    int n;
+    unsigned long long* slots[MAX];
+    unsigned long long* out[MAX];
+    int is_max[MAX];
+    int mode[MAX];
+};
 
 struct Ptr3 {
     double* p[3];
@@ -213,6 +224,7 @@ struct Launchers {
     int (*leaf_cons2prim)(long n, double mass, double gamma, const double* U, double* Q, double* sp, hipStream_t);
     int (*leaf_prim2cons)(long n, double mass, double gamma, const double* Q, double* U, hipStream_t);
     void (*reduce_final)(const double* part, int n, int is_max, unsigned long long* out, hipStream_t);
+    void (*reduce_many)(const RedJobs&, hipStream_t);
     // MFP::estTimeStep + computeNewDt on the device: log[idx] = dt[0]; dt[0] = min(cfl * est, 1.1 * dt[0])
     void (*new_dt)(const DtPlan&, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t);
 };
