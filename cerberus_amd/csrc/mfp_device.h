@@ -240,13 +240,17 @@ CMFP_DEV bool hydro_cons2prim(const GasP& G, const double* U, double* Q) {
     double ke = 0.5 * rho * (u * u + v * v + w * w);
     double g = G.gamma;
     double p = (ed - ke) * (g - 1);
-    double T = p * rhoinv * G.mass;
     Q[H_RHO] = rho;
     Q[H_U] = u;
     Q[H_V] = v;
     Q[H_W] = w;
     Q[H_P] = p;
+#ifdef CMFP_FASTMATH
+    return !((rho <= 0.0) || (p <= 0.0));  // T = p / rho * mass: its sign test adds nothing for mass > 0
+#else
+    double T = p * rhoinv * G.mass;
     return !((rho <= 0.0) || (p <= 0.0) || (T <= 0.0));
+#endif
 }
 // ThermallyPerfectGas::prim2cons :220-246
 CMFP_DEV void hydro_prim2cons(const GasP& G, const double* Q, double* U) {
@@ -280,7 +284,12 @@ CMFP_DEV void hydro_speed_from_cons(const GasP& G, const double* U, double* s) {
 }
 // ThermallyPerfectGas::get_speed_from_prim :319-332
 CMFP_DEV void hydro_speed_from_prim(const GasP& G, const double* Q, double* s) {
+#ifdef CMFP_FASTMATH
+    const double a2 = f_div(G.gamma * Q[H_P], Q[H_RHO]);
+    double a = a2 * f_rsqrt(a2);  // sqrt(x) = x rsqrt(x): valid states have x > 0
+#else
     double a = f_sqrt(f_div(G.gamma * Q[H_P], Q[H_RHO]));
+#endif
     s[0] = a + fabs(Q[H_U]);
     s[1] = a + fabs(Q[H_V]);
     s[2] = a + fabs(Q[H_W]);
@@ -301,13 +310,12 @@ struct HllAux {
 // HydroHLLC::solve MFP_hllc.cpp:30-185.  L, R in the face-normal frame.
 CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double gamR, double* F, HllAux* aux = nullptr) {
     double rhoL = L[H_RHO], uL = L[H_U], vL = L[H_V], wL = L[H_W], pL = L[H_P];
-    double nrgL = f_div(pL, gamL - 1) + 0.5 * rhoL * (uL * uL + vL * vL + wL * wL);
     double rhoR = R[H_RHO], uR = R[H_U], vR = R[H_V], wR = R[H_W], pR = R[H_P];
-    double nrgR = f_div(pR, gamR - 1) + 0.5 * rhoR * (uR * uR + vR * vR + wR * wR);
 #ifdef CMFP_FASTMATH
     const double rinvL = f_rcp(rhoL), rinvR = f_rcp(rhoR);  // reused for nrg / rho of the chosen side below
-    double aL = f_sqrt(gamL * pL * rinvL);
-    double aR = f_sqrt(gamR * pR * rinvR);
+    const double a2L = gamL * pL * rinvL, a2R = gamR * pR * rinvR;
+    double aL = a2L * f_rsqrt(a2L);  // sqrt(x) = x rsqrt(x): valid states have x > 0
+    double aR = a2R * f_rsqrt(a2R);
 #else
     double aL = f_sqrt(f_div(gamL * pL, rhoL));
     double aR = f_sqrt(f_div(gamR * pR, rhoR));
@@ -318,6 +326,14 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
     double p_star = 0.5 * (pL + pR) - 0.5 * (uR - uL) * rho_bar * a_bar;
     double S_star = 0.5 * (uL + uR) - f_div(0.5 * (pR - pL), rho_bar * a_bar);
 
+#ifdef CMFP_FASTMATH
+    // a_K q_K of :69-87 as one root without the division by p_K and without a branch:
+    //   a_K^2 q_K^2 = a_K^2 + (gamma_K + 1) / (2 rho_K) * max(p* - p_K, 0)      (a_K^2 / p_K = gamma_K / rho_K)
+    const double aq2L = fma(0.5 * (gamL + 1.0) * rinvL, fmax(p_star - pL, 0.0), a2L);
+    const double aq2R = fma(0.5 * (gamR + 1.0) * rinvR, fmax(p_star - pR, 0.0), a2R);
+    double S_L = uL - aq2L * f_rsqrt(aq2L);
+    double S_R = uR + aq2R * f_rsqrt(aq2R);
+#else
     double qL;
     if (p_star <= pL) {
         qL = 1.0;
@@ -332,6 +348,7 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
         qR = f_sqrt(1.0 + f_div(gamR + 1.0, 2 * gamR) * (f_div(p_star, pR) - 1.0));
     }
     double S_R = uR + aR * qR;
+#endif
 
     // The reference's four-way branch (MFP_hllc.cpp:92-184) written as a side
     // selection: every lane evaluates the same expressions on the state of the
@@ -342,7 +359,9 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
     const bool starR = !pureL && !starL && (S_star <= 0.0) && (0.0 <= S_R);
     const bool useL = pureL || starL;
     const double rho = useL ? rhoL : rhoR, u = useL ? uL : uR, v = useL ? vL : vR, w = useL ? wL : wR;
-    const double p = useL ? pL : pR, nrg = useL ? nrgL : nrgR, S_K = useL ? S_L : S_R;
+    const double p = useL ? pL : pR, S_K = useL ? S_L : S_R;
+    // nrg_K of :44,60 for the side in use only: the same expression on the same operands as the reference's
+    const double nrg = f_div(p, (useL ? gamL : gamR) - 1) + 0.5 * rho * (u * u + v * v + w * w);
     const double fv0 = rho * u;
     const double fv1 = rho * u * u + p;
     const double fv2 = rho * u * v;
@@ -350,7 +369,15 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
     const double fv4 = u * (nrg + p);
     if (starL || starR) {
         const double sv0 = rho, sv1 = rho * u, sv2 = rho * v, sv3 = rho * w, sv4 = nrg;
+#ifdef CMFP_FASTMATH
+        // 1 / (S_K - S*) and 1 / (rho (S_K - u)) from one reciprocal of their product
+        const double dSs = S_K - S_star, rdu = rho * (S_K - u);
+        const double rprod = f_rcp(dSs * rdu);
+        const double ratio = (S_K - u) * (rprod * rdu);
+        const double p_rdu = p * (rprod * dSs);
+#else
         const double ratio = f_div(S_K - u, S_K - S_star);
+#endif
         const double coeff = rho * ratio;
         if (aux) {
             aux->branch = 1;
@@ -367,7 +394,11 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
 #else
         const double nrg_rho = f_div(nrg, rho);
 #endif
+#ifdef CMFP_FASTMATH
+        const double ss4 = coeff * (nrg_rho + (S_star - u) * (S_star + p_rdu));
+#else
         const double ss4 = coeff * (nrg_rho + (S_star - u) * (S_star + f_div(p, rho * (S_K - u))));
+#endif
         F[0] = fv0 + S_K * (ss0 - sv0);
         F[1] = fv1 + S_K * (ss1 - sv1);
         F[2] = fv2 + S_K * (ss2 - sv2);

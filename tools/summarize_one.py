@@ -44,7 +44,7 @@ if f:
         dur[r["Name"]] = float(r["AverageNs"])
 res = {}
 for k in acc:
-    if not any(s in k for s in ("k_ctu", "k_f3d", "k_source", "k_g_", "k_fill", "k_pack", "k_proj", "k_fld")):
+    if not any(s in k for s in ("k_ctu", "k_f3d", "k_f3m", "k_source", "k_g_", "k_fill", "k_pack", "k_proj", "k_fld", "k_reduce", "k_new_dt", "k_ell")):
         continue
     e = {c: acc[k][c] / cnt[k][c] for c in acc[k]}
     e["launches_seen"] = max(cnt[k].values())
