@@ -312,10 +312,13 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
     double rhoL = L[H_RHO], uL = L[H_U], vL = L[H_V], wL = L[H_W], pL = L[H_P];
     double rhoR = R[H_RHO], uR = R[H_U], vR = R[H_V], wR = R[H_W], pR = R[H_P];
 #ifdef CMFP_FASTMATH
-    const double rinvL = f_rcp(rhoL), rinvR = f_rcp(rhoR);  // reused for nrg / rho of the chosen side below
-    const double a2L = gamL * pL * rinvL, a2R = gamR * pR * rinvR;
-    double aL = a2L * f_rsqrt(a2L);  // sqrt(x) = x rsqrt(x): valid states have x > 0
-    double aR = a2R * f_rsqrt(a2R);
+    // one reciprocal root per side: y = 1 / sqrt(gamma p rho) gives a = gamma p y, 1 / rho = a y, a^2 = a a
+    // (valid states have gamma p rho > 0); 1 / rho is reused for nrg / rho of the chosen side below
+    const double gpL = gamL * pL, gpR = gamR * pR;
+    const double yL = f_rsqrt(gpL * rhoL), yR = f_rsqrt(gpR * rhoR);
+    double aL = gpL * yL, aR = gpR * yR;
+    const double rinvL = aL * yL, rinvR = aR * yR;
+    const double a2L = aL * aL, a2R = aR * aR;
 #else
     double aL = f_sqrt(f_div(gamL * pL, rhoL));
     double aR = f_sqrt(f_div(gamR * pR, rhoR));
@@ -736,8 +739,15 @@ CMFP_DEV void hydro_cell_faces(const double gamma, const double (*st)[5], double
         phi_w = 0.0;
         phi_eps = 0.0;
     } else {
+#ifdef CMFP_FASTMATH
+        // the test of :948 multiplied through by rho_lo rho_hi (>= 0 after the clamp above): the quotient is only
+        // formed where the rescaling applies
+        if ((0.125 * abs_phi) * (rho_lo * rho_hi) > rho * eps_face) {
+            double coeff_eps = f_div(rho, rho_lo * rho_hi) * eps_face;
+#else
         double coeff_eps = f_div(rho, rho_lo * rho_hi) * eps_face;
         if ((0.125 * abs_phi) > coeff_eps) {
+#endif
             double phi_scale = f_sqrt(abs_phi);
             coeff_eps = f_sqrt(8 * coeff_eps);
             phi_u = f_div(phi_u, phi_scale) * coeff_eps;
