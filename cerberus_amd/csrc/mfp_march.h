@@ -109,6 +109,7 @@ static inline bool march_select(const Geo& g, int part, int ring, int mw, int mu
         if (seg3 >= 36) seg = seg3;
         static const int seg_min = std::getenv("CMFP_MARCH_SEG_MIN") ? std::atoi(std::getenv("CMFP_MARCH_SEG_MIN")) : 6;
         if (seg < seg_min) seg = seg_min;
+        seg += seg & 1;  // the kernel runs two rows per loop trip over seg + 2 rows
     }
     sel.seg = seg;
     sel.nwaves = 0;

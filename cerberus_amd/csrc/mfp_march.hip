@@ -104,7 +104,11 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
     for (int n = 0; n < 5; ++n) xlo_p[n] = xhi_p[n] = yhiU_p[n] = yhiC_p[n] = fy_p[n] = fy2_p[n] = 0.0;
     double red_speed = 2.2250738585072014e-308;  // std::numeric_limits<Real>::min(), MFP_eulerian.cpp:265
 
-    for (int r = ja - 1; r <= jb + 1; ++r) {
+    // One row of the march.  The loop below runs it twice per trip: what a row hands to the next one then
+    // alternates between two sets of registers instead of being copied (a value of row r is still in use
+    // while row r + 1 computes its own); a trip past the last row (odd row count) computes and drops a row.
+    auto march_row = [&](const int r) __attribute__((always_inline)) {
+        const bool live = r <= jb + 1;
         double Qc[5];
         to_prim(Un, Qc);
         {
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
             const bool col_in = inner && i >= 0 && i < n0;
             const bool ok_hi = Phys::correct(P, yhi, kx, dF);
             const bool ok_lo = Phys::correct(P, ylo, kx, dF);
-            if (col_in && ((!ok_hi && r < n1) || (!ok_lo && r >= 0 && r <= n1))) bad = true;
+            if (live && col_in && ((!ok_hi && r < n1) || (!ok_lo && r >= 0 && r <= n1))) bad = true;
         }
         if (r > ja) {  // x-face states of row r - 1 use F_y(r - 1) - F_y(r)
             double dF[5];
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
             const bool ok_hi = Phys::correct(P, xhi_p, ky, dF);
             const bool ok_lo = Phys::correct(P, xlo_p, ky, dF);
             const bool lane_ok = lane >= 1 && lane <= 62;
-            if (lane_ok && ((!ok_hi && i >= -1 && i < n0) || (!ok_lo && i >= 0 && i <= n0))) bad = true;
+            if (live && lane_ok && ((!ok_hi && i >= -1 && i < n0) || (!ok_lo && i >= 0 && i <= n0))) bad = true;
         }
 
         // ---- domain-face BCs (update_face_prim, do_all) + Riemann sweep 2
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
                 du += dtdy * (fy2_p[n] - fy2[n]);
                 Unew[n] = Uold[n] + du;
             }
-            if (upd) {
+            if (upd && live) {
                 const long c = col + (long)(r - 1) * g.sj;
 #pragma unroll
                 for (int n = 0; n < 5; ++n) Uout[c + n * g.sc] = Unew[n];
@@ -248,6 +252,10 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
             fy_p[n] = fy[n];
             fy2_p[n] = fy2[n];
         }
+    };
+    for (int r = ja - 1; r <= jb + 1; r += 2) {
+        march_row(r);
+        march_row(r + 1);
     }
     if (bad) *err = 1;
     if constexpr (REDUCE) {
