@@ -44,7 +44,7 @@ CMFP_DEV double o6_interface(double s1, double s2, double s3, double s4, double 
 }
 
 template <bool HAS_BC, int SRC>
-__global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldParams P, const double* __restrict__ Uin, double* __restrict__ Uout,
+__global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const double* __restrict__ Uin, double* __restrict__ Uout,
                                                       double dt, MarchBC bc, MarchSel sel, typename EpiArg<SRC>::type epi) {
     typedef FieldF<5> Phys;
     __shared__ double ring_[FLD_NR * 8 * 64 + 2 * FLD_PAD];
@@ -92,14 +92,16 @@ __global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldP
         auto slot_of = [&](int row) { return (row - row0) % FLD_NR; };
         auto at = [&](int slot, int n, int l) -> double& { return ring[(slot * 8 + n) * 64 + l]; };
 
-        // prologue: rows ja - 4 .. ja + 1 into the window; I_y(ja - 3/2) from them; row ja + 2 in flight
-        double Un[8];
+        // prologue: rows ja - 4 .. ja + 1 into the window; I_y(ja - 3/2) from them; rows ja + 2, ja + 3 in flight
+        // (two rows ahead: at one or two waves per SIMD nothing else hides the latency of the loads)
+        double Un[8], Un2[8];
         for (int s = 0; s < FLD_NR; ++s) {
             load_row(row0 + s, Un);
 #pragma unroll
             for (int n = 0; n < 8; ++n) at(s, n, lane) = Un[n];
         }
         load_row(ja + 2, Un);
+        load_row(ja + 3 < jb + 4 ? ja + 3 : jb + 4, Un2);
         double Iy_p[8];
 #pragma unroll
         for (int n = 0; n < 8; ++n)
@@ -112,31 +114,38 @@ __global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldP
         double fy_p[8], fy2_p[8];   // F_y and F'_y on the low y-face
 #pragma unroll
         for (int n = 0; n < 8; ++n) xlo_p[n] = xhi_p[n] = yhiU_p[n] = yhiC_p[n] = fy_p[n] = fy2_p[n] = 0.0;
-        // source epilogue: the species' values of the row that is updated in the next iteration, requested one
-        // iteration ahead (at one wave per SIMD nothing else hides their latency)
-        double sp_cur[SRC > 0 ? SRC : 1][5], sp_nxt[SRC > 0 ? SRC : 1][5];
+        // source epilogue: the species' values of the row that is updated two iterations later, requested now
+        double sp_cur[SRC > 0 ? SRC : 1][5], sp_nxt[SRC > 0 ? SRC : 1][5], sp_nx2[SRC > 0 ? SRC : 1][5];
 #pragma unroll
         for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s)
 #pragma unroll
-            for (int n = 0; n < 5; ++n) sp_cur[s][n] = sp_nxt[s][n] = 1.0;
+            for (int n = 0; n < 5; ++n) sp_cur[s][n] = sp_nxt[s][n] = sp_nx2[s][n] = 1.0;
 
-        for (int r = ja - 1; r <= jb + 1; ++r) {
-            // ---- row r + 3 enters the window (it replaces row r - 3); row r + 4 is requested
+        // One row of the march.  The loop below runs it twice per trip: what a row hands to the next one then
+        // alternates between two sets of registers instead of being copied; a trip past the last row (odd row
+        // count) computes and drops a row.
+        auto march_row = [&](const int r) __attribute__((always_inline)) {
+            const bool live = r <= jb + 1;
+            // ---- row r + 3 enters the window (it replaces row r - 3); row r + 5 is requested
             __syncthreads();  // every lane has finished reading the slot that is overwritten
             {
                 const int sn = slot_of(r + 3);
 #pragma unroll
-                for (int n = 0; n < 8; ++n) at(sn, n, lane) = Un[n];
-                const int rn = r + 4 < jb + 4 ? r + 4 : jb + 4;  // rows past the segment's stencil reach are not touched
-                load_row(rn, Un);
+                for (int n = 0; n < 8; ++n) {
+                    at(sn, n, lane) = Un[n];
+                    Un[n] = Un2[n];
+                }
+                const int rn = r + 5 < jb + 4 ? r + 5 : jb + 4;  // rows past the segment's stencil reach are not touched
+                load_row(rn, Un2);
                 if constexpr (SRC > 0) {
-                    if (upd && r >= ja && r <= jb) source_epilogue_load<SRC>(g, epi, col + (long)r * g.sj, sp_nxt);
+                    if (upd && r + 1 >= ja && r + 1 <= jb) source_epilogue_load<SRC>(g, epi, col + (long)(r + 1) * g.sj, sp_nx2);
                 }
             }
             __syncthreads();
             // The phases below are ordered so that what is carried from row r - 1 is consumed (and its registers
-            // reused) as early as possible; the scheduling fences keep the compiler from interleaving them, which
-            // would push the live state of the iteration beyond the register file.
+            // reused) as early as possible.  One wave per SIMD (launch bounds): the iteration's live state plus the
+            // rows in flight need about 400 registers; at two waves per SIMD the kernel spilled to scratch and ran
+            // 1.25 ms instead of 0.76 ms (4096^2, without the epilogue).
             const int s0 = slot_of(r - 2), s1 = slot_of(r - 1), s2 = slot_of(r), s3 = slot_of(r + 1), s4 = slot_of(r + 2),
                       s5 = slot_of(r + 3);
             // ---- A: y interface values, face states and half-step trace of row r
@@ -152,14 +161,16 @@ __global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldP
             }
             ylo[8] = ylo[9] = mlo[1];
             yhi[8] = yhi[9] = mhi[1];
-            if constexpr (SRC == 0) __builtin_amdgcn_sched_barrier(0);
             // ---- B: Riemann sweep 1 on the low y-face of (i, r); C: with it, the x-face states of row r - 1 get their
             //      transverse correction F_y(r - 1) - F_y(r) (EulerianState::correct_face_prim MFP_eulerian.cpp:1047-1188,
             //      per cell), then domain-face BCs (update_face_prim, do_all) and Riemann sweep 2 in x for row r - 1
-            double fx2[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // (No test of r against ja here or below: the first two rows of a segment run the same arithmetic on
+            //  what the carried registers hold — zeros, then row ja - 1 — which is finite for this linear solver;
+            //  nothing of it reaches a stored value, stores start at r = ja + 1.)
+            double fx2[10];
             {
-                double fy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                if (r >= ja) {
+                double fy[10];
+                {
                     double L[10];
 #pragma unroll
                     for (int n = 0; n < 8; ++n) L[n] = yhiU_p[n];
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldP
                 }
 #pragma unroll
                 for (int n = 0; n < 8; ++n) yhiU_p[n] = yhi[n];
-                if (r > ja) {
+                {
                     double dF[8];
 #pragma unroll
                     for (int n = 0; n < 8; ++n) dF[n] = fy_p[n] - fy[n];
@@ -197,7 +208,6 @@ __global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldP
 #pragma unroll
                 for (int n = 0; n < 8; ++n) fy_p[n] = fy[n];
             }
-            if constexpr (SRC == 0) __builtin_amdgcn_sched_barrier(0);
             // ---- D: x interface values, face states, trace and Riemann sweep 1 of row r; the y-face states of row r
             //      get their transverse correction F_x(i) - F_x(i + 1)
             {
@@ -229,10 +239,9 @@ __global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldP
                 Phys::correct(P, yhi, hx, dF);
                 Phys::correct(P, ylo, hx, dF);
             }
-            if constexpr (SRC == 0) __builtin_amdgcn_sched_barrier(0);
             // ---- E: domain-face BCs + Riemann sweep 2 on the low y-face of (i, r)
-            double fy2[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (r >= ja) {
+            double fy2[10];
+            {
                 double L[10], Rr[10];
 #pragma unroll
                 for (int n = 0; n < 8; ++n) {
@@ -255,9 +264,8 @@ __global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldP
             }
 #pragma unroll
             for (int n = 0; n < 8; ++n) yhiC_p[n] = yhi[n];
-            if constexpr (SRC == 0) __builtin_amdgcn_sched_barrier(0);
             // ---- F: divergence of row r - 1 (calc_divergence MFP_eulerian.cpp:1614-1662), new += dU, [source stage C]
-            if (r > ja) {
+            {
                 double Unew[10];
 #pragma unroll
                 for (int n = 0; n < 8; ++n) {
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldP
                     Unew[n] = at(s1, n, lane) + du;
                 }
                 Unew[8] = Unew[9] = 1.0;  // mu, ep: F = 0 (MFP_field_RH.cpp:33), vacuum block
-                if (upd) {
+                if (upd && live && r > ja) {
                     const long c = col + (long)(r - 1) * g.sj;
                     if constexpr (SRC > 0) source_epilogue_cell_pre<SRC>(g, epi, dt, c, Unew, sp_cur, src_speed, src_dt);
 #pragma unroll
@@ -281,8 +289,15 @@ __global__ __launch_bounds__(64, SRC > 0 ? 1 : 2) void k_fld_march(Geo g, FieldP
 #pragma unroll
                 for (int s = 0; s < SRC; ++s)
 #pragma unroll
-                    for (int n = 0; n < 5; ++n) sp_cur[s][n] = sp_nxt[s][n];
+                    for (int n = 0; n < 5; ++n) {
+                        sp_cur[s][n] = sp_nxt[s][n];
+                        sp_nxt[s][n] = sp_nx2[s][n];
+                    }
             }
+        };
+        for (int r = ja - 1; r <= jb + 1; r += 2) {
+            march_row(r);
+            march_row(r + 1);
         }
     }
     if constexpr (SRC > 0) {
@@ -338,12 +353,13 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
     static const int seg_env = std::getenv("CMFP_FIELD_SEG") ? std::atoi(std::getenv("CMFP_FIELD_SEG")) : 0;
     int seg = seg_env;
     if (seg <= 0) {
-        const int rounds = (epi ? fld_wave_slots() * 4 / 6 : fld_wave_slots()) / R.ns;  // with the epilogue: one wave per SIMD
+        const int rounds = fld_wave_slots() * 4 / 6 / R.ns;  // one wave per SIMD (the kernel's register budget)
         seg = rounds > 0 ? (g.n[1] + rounds - 1) / rounds : g.n[1];
         // small blocks: short segments that put one wave on every SIMD beat long ones on a few (512^2: 6 rows
         // against 24, launch 0.10 -> see DESIGN.md section 3); the eight rows of start-up only cost where waves queue
         static const int seg_min = std::getenv("CMFP_FIELD_SEG_MIN") ? std::atoi(std::getenv("CMFP_FIELD_SEG_MIN")) : 6;
         if (seg < seg_min) seg = seg_min;
+        seg += seg & 1;  // the kernel runs two rows per loop trip over seg + 2 rows
     }
     if (seg > g.n[1]) seg = g.n[1];
     sel.seg = seg;
