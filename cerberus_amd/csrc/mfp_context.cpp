@@ -92,6 +92,8 @@ struct cmfp_context {
     hipStream_t stream2 = nullptr;  // interior tiles run here while ghost cells are in flight on `stream`
     hipEvent_t ev_src = nullptr, ev_int = nullptr, ev_hyd = nullptr;  // one callback per dimension for all states (state = CMFP_ALL_STATES)
     int* d_err = nullptr;
+    unsigned long long* d_errcell = nullptr;  // scratch word of the post-mortem scan (first_invalid)
+    int err_state = -1, err_cell[3] = {-1, -1, -1};  // first offending cell of the last CMFP_ERR_PHYSICS, if one was found
     int* d_flag = nullptr;      // result word of one-off device checks
     double* d_dtbuf = nullptr;  // cmfp_advance_steps: device-resident dt + dt log
     int d_dtcap = 0;
@@ -973,8 +975,29 @@ int sync_and_check(cmfp_context* c) {
     int h_err = 0;
     HIPCHK(c, hipMemcpyAsync(&h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (h_err) return fail(c, CMFP_ERR_PHYSICS, "Primitive values outside of physical bounds!!");
-    return CMFP_OK;
+    if (!h_err) return CMFP_OK;
+    // Post-mortem: the first cell (state order, then memory order) whose cell-centred values are invalid now.  The
+    // kernels flag invalid *face* states too (after reconstruction or a transverse correction); those leave no
+    // invalid cell behind and are reported without a location.
+    std::string where = " (no cell-centred value is invalid: a face state failed after reconstruction or transverse correction)";
+    c->err_state = -1;
+    for (size_t s = 0; s < c->states.size() && c->err_state < 0; ++s) {
+        if (c->states[s].sp.kind != CMFP_STATE_HYDRO) continue;
+        unsigned long long h = ~0ull;
+        if (hipMemsetAsync(c->d_errcell, 0xff, sizeof(h), c->stream) != hipSuccess) break;
+        c->L->first_invalid(c->g, c->states[s].sp, c->states[s].new_data, c->d_errcell, c->stream);
+        if (hipMemcpyAsync(&h, c->d_errcell, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess) break;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) break;
+        if (h == ~0ull) continue;
+        c->err_state = (int)s;
+        c->err_cell[0] = (int)(h % (unsigned long long)c->g.n[0]);
+        c->err_cell[1] = (int)((h / (unsigned long long)c->g.n[0]) % (unsigned long long)c->g.n[1]);
+        c->err_cell[2] = (int)(h / ((unsigned long long)c->g.n[0] * (unsigned long long)c->g.n[1]));
+        where = " first offending cell: state " + std::to_string(s) + ", cell (" + std::to_string(c->err_cell[0]) + ", " +
+                std::to_string(c->err_cell[1]) + ", " + std::to_string(c->err_cell[2]) + ") of this block";
+    }
+    (void)hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream);  // the flag is per failure, not sticky
+    return fail(c, CMFP_ERR_PHYSICS, "Primitive values outside of physical bounds!!" + where);
 }
 
 }  // namespace
@@ -1104,6 +1127,7 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
                 return fail(c, CMFP_ERR_INVALID, "source action: species must be hydro states");
     }
     HIPCHK(c, hipMalloc((void**)&c->d_err, sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->d_errcell, sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
     HIPCHK(c, hipMalloc((void**)&c->d_flag, sizeof(int)));
     HIPCHK(c, hipMalloc((void**)&c->d_red, sizeof(unsigned long long) * (2 * n_states + n_actions + 1)));
@@ -1143,6 +1167,7 @@ int cmfp_destroy(cmfp_context* c) {
     }
     for (double* p : c->allocs) (void)hipFree(p);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_errcell) (void)hipFree(c->d_errcell);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_dtbuf) (void)hipFree(c->d_dtbuf);
     cmfp_ell::release(c->ell);
@@ -1153,6 +1178,13 @@ int cmfp_destroy(cmfp_context* c) {
 }
 
 const char* cmfp_last_error(const cmfp_context* c) { return c ? c->err.c_str() : "null context"; }
+
+int cmfp_last_error_cell(const cmfp_context* c, int* state, int* cell) {
+    if (!c || !state || !cell) return CMFP_ERR_INVALID;
+    *state = c->err_state;
+    for (int d = 0; d < 3; ++d) cell[d] = c->err_cell[d];
+    return c->err_state >= 0 ? CMFP_OK : CMFP_ERR_INVALID;
+}
 
 int cmfp_state_ncomp(const cmfp_context* c, int s) {
     return (c && s >= 0 && s < (int)c->states.size()) ? c->states[s].sp.nc : CMFP_ERR_INVALID;

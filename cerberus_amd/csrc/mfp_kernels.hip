@@ -654,6 +654,23 @@ __global__ __launch_bounds__(256) void k_reduce_many(RedJobs J) {
     }
     slots[threadIdx.x] = identity;
 }
+// post-mortem of a failed step: the first valid cell (in memory order) of a hydro state without valid primitives
+__global__ void k_first_invalid(Geo g, IBox box, HydroParams hp, const double* __restrict__ U, unsigned long long* out) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long t = g.at(i, j, k);
+    double u[5], q[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) u[n] = U[t + n * g.sc];
+    const double T = (u[4] - 0.5 * (u[1] * u[1] + u[2] * u[2] + u[3] * u[3]) / u[0]) * (hp.gas.gamma - 1) / u[0] * hp.gas.mass;
+    if (!hydro_cons2prim(hp.gas, u, q) || !(T > 0.0))  // NaNs count as invalid here
+        atomicMin(out, (unsigned long long)(((long)k * g.n[1] + j) * g.n[0] + i));
+}
+static void l_first_invalid(const Geo& g, const StatePhys& sp, const double* U, unsigned long long* out, hipStream_t st) {
+    IBox b = valid_box(g);
+    const long np = b.npts();
+    hipLaunchKernelGGL(k_first_invalid, dim3((unsigned)((np + TPB - 1) / TPB)), dim3(TPB), 0, st, g, b, sp.hp, U, out);
+}
 static void l_reduce_many(const RedJobs& J, hipStream_t st) {
     if (J.n > 0) hipLaunchKernelGGL(k_reduce_many, dim3(J.n), dim3(256), 0, st, J);
 }
@@ -1436,7 +1453,7 @@ const Launchers* launchers() {
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack, l_fill_multi,
                                 ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, ctu_field_src, ctu_march2, ctu_march_field, field_vacuum_check, l_source_coef, l_source_fused_box, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
-                                l_leaf_prim2cons, l_reduce_final, l_reduce_many, l_new_dt};
+                                l_leaf_prim2cons, l_reduce_final, l_reduce_many, l_first_invalid, l_new_dt};
     return &L;
 }
 

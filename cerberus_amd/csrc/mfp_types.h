@@ -225,6 +225,9 @@ struct Launchers {
     int (*leaf_prim2cons)(long n, double mass, double gamma, const double* Q, double* U, hipStream_t);
     void (*reduce_final)(const double* part, int n, int is_max, unsigned long long* out, hipStream_t);
     void (*reduce_many)(const RedJobs&, hipStream_t);
+    // *out (all-ones before the launch) becomes the smallest (k * n1 + j) * n0 + i of the valid cells of a hydro state
+    // whose conserved values do not give valid primitives (HydroGas::prim_valid MFP_hydro_gas.cpp:152-164)
+    void (*first_invalid)(const Geo&, const StatePhys&, const double* U, unsigned long long* out, hipStream_t);
     // MFP::estTimeStep + computeNewDt on the device: log[idx] = dt[0]; dt[0] = min(cfl * est, 1.1 * dt[0])
     void (*new_dt)(const DtPlan&, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t);
 };

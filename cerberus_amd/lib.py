@@ -41,6 +41,7 @@ SYMBOLS = [
     ("cmfp_advance_steps", C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, dp, dp]),
     ("cmfp_advance_steps_static", C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, dp, dp]),
     ("cmfp_elliptic_project", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    ("cmfp_last_error_cell", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("cmfp_set_fused", C.c_int, [C.c_void_p, C.c_int]),
     ("cmfp_last_advance_fused", C.c_int, [C.c_void_p]),
     ("cmfp_profile_enable", C.c_int, [C.c_void_p, C.c_int]),

@@ -228,6 +228,15 @@ class MFP:
         """0: staged kernels, 1: tiled fused kernels, 2: gather kernels (1-D / 3-D, or forced with fused=2)."""
         return int(self.L.cmfp_last_advance_fused(self.h))
 
+    def last_error_cell(self):
+        """(state index, (i, j, k)) of the first offending cell of the last ERR_PHYSICS, or None where the
+        failure left no invalid cell-centred value (cmfp_last_error_cell)."""
+        import ctypes as C
+        st, cell = C.c_int(-1), (C.c_int * 3)()
+        if self.L.cmfp_last_error_cell(self.h, C.byref(st), cell) != 0:
+            return None
+        return st.value, tuple(cell)
+
     def host_times(self, reset=False):
         """Host seconds spent inside the exchange and dt-reduce hooks (ranks > 1): enqueue cost on the host,
         not device time; everything in them is asynchronous with a device-to-device transport."""

@@ -184,6 +184,12 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
                 int device, void* stream, cmfp_context** out);
 int cmfp_destroy(cmfp_context* ctx);
 const char* cmfp_last_error(const cmfp_context* ctx);
+/* The first offending cell of the last CMFP_ERR_PHYSICS ("error flag + first offending
+ * cell"; the reference aborts inside HydroGas::prim_valid, MFP_hydro_gas.cpp:152-164, without a location): index of
+ * the hydro state and block-local (i, j, k) of the first valid cell, in state then memory order, whose cell-centred
+ * values are invalid when the failure is detected.  CMFP_ERR_INVALID (state = -1) if the last error was another one,
+ * or if only a face state failed (after reconstruction / transverse correction), which leaves no invalid cell. */
+int cmfp_last_error_cell(const cmfp_context* ctx, int* state, int* cell /* [3] */);
 
 /* Number of conserved comps / ghost width (Reconstruction::num_grow,
  * MFP_reconstruction.cpp:60,82,124,164,217,248,284) of a state. */

@@ -175,6 +175,15 @@ def test_unphysical_state_is_reported_not_aborted():
     with pytest.raises(lib.CmfpError) as e:
         m.download(0)
     assert e.value.code == abi.ERR_PHYSICS
+    # error flag + first offending cell.  The scan runs when the failure is detected, after the step
+    # has spread the invalid value over the stencil reach of cell (10, 10)
+    st, cell = m.last_error_cell()
+    assert st == 0 and cell[2] == 0 and abs(cell[0] - 10) <= 4 and abs(cell[1] - 10) <= 4, (st, cell)
+    assert "first offending cell" in str(e.value)
+    # the flag is per failure: a valid state afterwards runs again
+    m.upload(0, P.initial_data(0))
+    m.advance(1e-4)
+    m.download(0)
     m.close()
 
 
