@@ -766,7 +766,18 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
             // split launches: the field's interior launch reads the species at its cells on the second stream,
             // so its interior must lie inside every species' interior (launched before it on that stream):
             // true when the species' stencils are no wider than the field's
-            if (overlap) ok = ok && c->states[SA.states[n]].sp.ng <= c->states[fs].sp.ng;
+            if (overlap) {
+                ok = ok && c->states[SA.states[n]].sp.ng <= c->states[fs].sp.ng;
+                // ... checked on the rectangles the launches themselves select (tile shapes and frame widths are
+                // build and kernel options): otherwise stage C stays a launch of its own
+                IBox fi, si;
+                int sp_flag = 1;
+                for (size_t q = 0; q < list.size(); ++q)
+                    if (list[q] == SA.states[n]) sp_flag = ctu_flag[q];
+                if (ok && c->L->ctu_interior(c->g, c->states[fs].sp, ctu_flag[epi_q >= 0 ? epi_q : 0], tile_flag, &fi) &&
+                    c->L->ctu_interior(c->g, c->states[SA.states[n]].sp, sp_flag, tile_flag, &si))
+                    for (int d = 0; d < 2; ++d) ok = ok && fi.lo[d] >= si.lo[d] && fi.hi[d] <= si.hi[d];
+            }
         }
         if (ok) {
             epi.ns = SA.n_states - 1;

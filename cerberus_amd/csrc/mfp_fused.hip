@@ -403,6 +403,23 @@ static FaceBC make_bc(const StatePhys& sp, const int touches[3][2]) {
     return b;
 }
 
+// interior tiles of a launch (part 1): footprint [i0 - 1 - H, i0 + TX + H] inside [0, n - 1]; returns their number
+template <int TX, int TY, int H> static int tile_interior(const Geo& g, TileSel& sel) {
+    sel.ix0 = sel.iy0 = 1;
+    sel.ix1 = g.n[0] - 1 - H - TX >= 0 ? (g.n[0] - 1 - H - TX) / TX : -1;
+    sel.iy1 = g.n[1] - 1 - H - TY >= 0 ? (g.n[1] - 1 - H - TY) / TY : -1;
+    return (sel.ix1 >= sel.ix0 && sel.iy1 >= sel.iy0) ? (sel.ix1 - sel.ix0 + 1) * (sel.iy1 - sel.iy0 + 1) : 0;
+}
+// the cells those tiles update
+template <int BX, int BY, int H> static bool tile_interior_box(const Geo& g, IBox& box) {
+    TileSel sel;
+    if (tile_interior<BX - 2, BY - 2, H>(g, sel) <= 0) return false;
+    box.lo[0] = sel.ix0 * (BX - 2), box.hi[0] = (sel.ix1 + 1) * (BX - 2) - 1;
+    box.lo[1] = sel.iy0 * (BY - 2), box.hi[1] = (sel.iy1 + 1) * (BY - 2) - 1;
+    box.lo[2] = box.hi[2] = 0;
+    return true;
+}
+
 template <class Phys, int BX, int BY>
 static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhys& sp, const double* Uin, double* Uout,
                     int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, int part,
@@ -413,11 +430,7 @@ static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhy
     sel.part = part;
     sel.gx = (g.n[0] + TX - 1) / TX;
     sel.gy = (g.n[1] + TY - 1) / TY;
-    // interior tiles: footprint [i0 - 1 - H, i0 + TX + H] inside [0, n - 1]
-    sel.ix0 = sel.iy0 = 1;
-    sel.ix1 = g.n[0] - 1 - H - TX >= 0 ? (g.n[0] - 1 - H - TX) / TX : -1;
-    sel.iy1 = g.n[1] - 1 - H - TY >= 0 ? (g.n[1] - 1 - H - TY) / TY : -1;
-    const int n_int = (sel.ix1 >= sel.ix0 && sel.iy1 >= sel.iy0) ? (sel.ix1 - sel.ix0 + 1) * (sel.iy1 - sel.iy0 + 1) : 0;
+    const int n_int = tile_interior<TX, TY, H>(g, sel);
     if (!Uin) return n_int > 0;  // split probe: is there an interior to overlap with?
     sel.n = part == 0 ? sel.gx * sel.gy : part == 1 ? n_int : sel.gx * sel.gy - n_int;
     if (sel.n <= 0) return 1;
@@ -447,10 +460,7 @@ static int launch2d_src(const Geo& g, const typename Phys::Params& P, const Stat
     sel.part = part;
     sel.gx = (g.n[0] + TX - 1) / TX;
     sel.gy = (g.n[1] + TY - 1) / TY;
-    sel.ix0 = sel.iy0 = 1;
-    sel.ix1 = g.n[0] - 1 - H - TX >= 0 ? (g.n[0] - 1 - H - TX) / TX : -1;
-    sel.iy1 = g.n[1] - 1 - H - TY >= 0 ? (g.n[1] - 1 - H - TY) / TY : -1;
-    const int n_int = (sel.ix1 >= sel.ix0 && sel.iy1 >= sel.iy0) ? (sel.ix1 - sel.ix0 + 1) * (sel.iy1 - sel.iy0 + 1) : 0;
+    const int n_int = tile_interior<TX, TY, H>(g, sel);
     sel.n = part == 0 ? sel.gx * sel.gy : part == 1 ? n_int : sel.gx * sel.gy - n_int;
     if (sel.n <= 0) return 1;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
@@ -520,6 +530,19 @@ int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout
 #undef HY
 #undef FI
     return 0;
+}
+
+// The cells the interior launch (part 1) of ctu_fused / ctu_field_src updates for this state, from the same
+// selection code the launches use.  The split launches with the source epilogue rely on: field interior inside
+// every species' interior (the context checks it with this).  false: no such launch / no interior.
+bool ctu_march_interior(const Geo& g, const StatePhys& sp, int do_ctu, IBox& box);
+int ctu_interior(const Geo& g, const StatePhys& sp, int do_ctu, int flags, IBox* box) {
+    if (g.dim != 2) return 0;
+    if (!(flags & 0x100) && ctu_march_interior(g, sp, do_ctu, *box)) return 1;
+    constexpr int HH = ReconTraits<1>::SL / 2;  // the tiled hydro kernels: three-point reconstructions
+    if (sp.kind == 0) return tile_interior_box<CMFP_HBX, CMFP_HBY, HH>(g, *box);
+    if (sp.recon == 5 || sp.recon == 6) return tile_interior_box<CMFP_FBX, CMFP_FBY, ReconTraits<5>::SL / 2>(g, *box);
+    return tile_interior_box<CMFP_FBX, CMFP_FBY, ReconTraits<1>::SL / 2>(g, *box);
 }
 
 // The tiled 2-D field update followed, per cell, by the explicit Strang source stage C of epi.ns species

@@ -65,9 +65,17 @@ static inline int wave_slots() {
 // the update), mw = columns a strip updates, mult = waves per (strip, segment) (field: one per
 // component group).  part 0 all cells, 1 the interior (stencil footprint inside valid cells), 2 the
 // frame around it.  Returns false when the launch is empty.
+// the cells of the interior launch (part 1): stencil footprint (+- ring) inside the valid cells
+static inline bool march_interior(const Geo& g, int ring, IBox& box) {
+    box.lo[0] = ring, box.hi[0] = g.n[0] - 1 - ring;
+    box.lo[1] = ring, box.hi[1] = g.n[1] - 1 - ring;
+    box.lo[2] = box.hi[2] = 0;
+    return box.hi[0] >= box.lo[0] && box.hi[1] >= box.lo[1];
+}
 static inline bool march_select(const Geo& g, int part, int ring, int mw, int mult, MarchSel& sel) {
     const int n0 = g.n[0], n1 = g.n[1];
-    const bool has_int = n0 >= 2 * ring + 1 && n1 >= 2 * ring + 1;
+    IBox inner;
+    const bool has_int = march_interior(g, ring, inner);
     sel.nrect = 0;
     auto add = [&](int ilo, int ihi, int jlo, int jhi) {
         if (ihi < ilo || jhi < jlo) return;
@@ -83,7 +91,7 @@ static inline bool march_select(const Geo& g, int part, int ring, int mw, int mu
     if (part == 0 || (part == 2 && !has_int)) {
         add(0, n0 - 1, 0, n1 - 1);
     } else if (part == 1) {
-        add(fx, n0 - 1 - fx, fy, n1 - 1 - fy);
+        add(inner.lo[0], inner.hi[0], inner.lo[1], inner.hi[1]);
     } else {
         add(0, n0 - 1, 0, fy - 1);
         add(0, n0 - 1, n1 - fy, n1 - 1);

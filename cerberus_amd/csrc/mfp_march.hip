@@ -312,6 +312,13 @@ int ctu_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout
     return 0;
 }
 
+// the cells ctu_march's interior launch (part 1) updates; false: ctu_march does not cover the state or has no interior
+bool ctu_march_interior(const Geo& g, const StatePhys& sp, int do_ctu, IBox& box) {
+    const int none[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    if (!ctu_march(g, sp, nullptr, nullptr, do_ctu, 0.0, none, nullptr, nullptr, 0, nullptr)) return false;
+    return march_interior(g, 2, box);
+}
+
 // Two hydro states in one launch (see MarchStates).  Returns 0 — nothing launched — unless both are covered
 // by ctu_march with the same kernel instance and the same domain-face rules; Uin[0] == nullptr probes.
 int ctu_march2(const Geo& g, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,

@@ -205,6 +205,8 @@ struct Launchers {
     // the tiled 2-D field update with the explicit Strang source stage C as its epilogue (mfp_fused.hip)
     int (*ctu_field_src)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
                          const int touches[3][2], const SourceEpi& epi, int part, hipStream_t);
+    // the cells the interior launch (part 1) of ctu_fused / ctu_field_src updates (flags: bit 8 as in their `part`)
+    int (*ctu_interior)(const Geo&, const StatePhys&, int do_ctu, int flags, IBox* box);
     // two 2-D hydro states of the same physics in one wave-marching launch (mfp_march.hip); 0: not covered, nothing launched
     int (*ctu_march2)(const Geo&, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
                       const int touches[3][2], int* err, unsigned long long* const red[2], int part, hipStream_t);
