@@ -14,6 +14,7 @@ int main(int argc, char** argv) {
     const int n = argc > 1 ? std::atoi(argv[1]) : 32;
     const int steps = argc > 2 ? std::atoi(argv[2]) : 5;
     const bool batch = argc > 3 && std::string(argv[3]) == "batch";
+    const bool project = argc > 3 && std::string(argv[3]) == "elliptic";  // + the divergence projection after every step
     const double gam = 5.0 / 3.0, c = 20.0, PI = std::acos(-1.0), L = 2 * PI;
     try {
         MFP level;
@@ -52,6 +53,11 @@ int main(int argc, char** argv) {
         A["plasma"].type = "plasma5";
         A["plasma"].solver = "explicit";
         A["plasma"].states = {"ion", "electron", "field"};
+        if (project) {
+            A["divergence_cleaning"].type = "elliptic";
+            A["divergence_cleaning"].projection = 1;
+            A["divergence_cleaning"].state = "field";
+        }
         level.read_config(S, A);
 
         // initial data (HydroState::init_data MFP_hydro.cpp:504-567): cell centres, prim2cons

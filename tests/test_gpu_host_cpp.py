@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", [[], ["batch"]], ids=["per_step", "advance_steps"])
+@pytest.mark.parametrize("mode", [[], ["batch"], ["elliptic"]], ids=["per_step", "advance_steps", "elliptic_action"])
 def test_cpp_host_demo_matches_python_driver(mode):
     from cerberus_amd.mfp import MFP
     exe = os.path.join(ROOT, "cerberus_amd", "host", "host_demo")
@@ -21,7 +21,10 @@ def test_cpp_host_demo_matches_python_driver(mode):
     assert out.returncode == 0, out.stderr
     dts = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("dt ")]
     sums = {l.split()[1]: (float(l.split()[3]), float(l.split()[5])) for l in out.stdout.splitlines() if l.startswith("state ")}
-    P = config.Problem(problems.orszag_tang_two_fluid_2d(32), fp_mode=abi.FP_STRICT)
+    cfg = problems.orszag_tang_two_fluid_2d(32)
+    if mode == ["elliptic"]:   # the mirror's Elliptic class (apply_change after every step, MFP_advance.cpp:49)
+        cfg["actions"]["divergence_cleaning"] = {"type": "elliptic", "projection": 1, "state": "field"}
+    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
     m = MFP(P)
     m.init_data()
     ref_dts = m.run(5)
