@@ -258,13 +258,16 @@ def main():
         # `roofline_other`.  achieved = algorithmic bytes per launch / mean launch time (HIP events on the
         # library's stream); in 3-D a "launch" of the field family is its plane-tile launches of one step together.
         pmc, pmc_path = pmc_file(workload, n) if fp == "fast" else ({}, None)
+        n_hydro = sum(1 for nm in P.state_names if P.cfg["states"][nm]["type"] == "hydro")
 
-        def roof_of(slot, bytes_per_cell, kname, per_update, pmc_subs):
+        def roof_of(slot, bytes_per_cell, kname, per_update, pmc_subs, states_per_step=1):
+            # per_update: launches that together make one update (the 3-D field family); states_per_step: states
+            # of the family one step updates (two species can share one marching launch)
             launches, ms = prof[slot]
             if not launches:
                 return None
             updates = launches / per_update
-            algo = float(bytes_per_cell) * cells
+            algo = float(bytes_per_cell) * cells * states_per_step * tsteps / updates
             achieved = algo / (ms / updates * 1e-3) / 1e9
             e = None
             traffic = None
@@ -283,7 +286,7 @@ def main():
             return r
 
         if dim == 3:
-            hroof = roof_of(0, 80, "k_ctu3d<HydroF<minmod,HLLC>> (z-marching fused CTU update of one hydro state)", 1, [("k_ctu3d",)])
+            hroof = roof_of(0, 80, "k_ctu3d<HydroF<minmod,HLLC>> (z-marching fused CTU update of one hydro state)", 1, [("k_ctu3d",)], n_hydro)
             per = prof[1][0] / tsteps if prof[1][0] else 1
             epilogue = prof[2][0] == tsteps
             froof = roof_of(1, 320 if epilogue else 160,
@@ -291,8 +294,9 @@ def main():
                             per, [("k_f3m_y1",), ("k_f3m_z1",), ("k_f3m_z<",), ("k_f3m_yx<",)])
         else:
             hname = ("k_ctu2d<HydroF<minmod,HLLC>> (LDS-tiled fused CTU update of one hydro state)" if args.tiled_hydro
-                     else "k_ctu_march<HydroF<minmod,HLLC>> (wave-marching fused CTU update of one hydro state)")
-            hroof = roof_of(0, 80, hname, 1, [("k_ctu2d<fast::HydroF",) if args.tiled_hydro else ("k_ctu_march",)])
+                     else "k_ctu_march<HydroF<minmod,HLLC>> (wave-marching fused CTU update of the hydro states: %d per launch)"
+                     % max(1, round(n_hydro * tsteps / max(1, prof[0][0]))))
+            hroof = roof_of(0, 80, hname, 1, [("k_ctu2d<fast::HydroF",) if args.tiled_hydro else ("k_ctu_march",)], n_hydro)
             froof = None
             if prof[1][0] == tsteps:   # one field launch per step (no interior / frame split)
                 epilogue = prof[2][0] == tsteps     # one separate source launch per step: stage C is in the field kernel
