@@ -597,7 +597,40 @@ class Interpreter:
             "tanh": m1(math.tanh), "sinh": m1(math.sinh), "cosh": m1(math.cosh), "maxinteger": float(2 ** 63 - 1),
             "mininteger": float(-2 ** 63), "tointeger": lambda x: (float(x) if float(x).is_integer() else None),
             "modf": lambda x: [float(math.trunc(_tonumber(x))), _tonumber(x) - math.trunc(_tonumber(x))],
+            "rad": m1(math.radians), "deg": m1(math.degrees),
         }))
+
+        # `PolySpline` is registered by the reference's embedded-boundary module (modules/eb/MFP_polyspline.cpp,
+        # MFP_config.cpp) for geometry scripts.  EB is outside this path (its tables are listed as ignored), but the
+        # shipped inputs build splines at load time: the constructor and the builders record their arguments, only
+        # a query — which nothing on this path makes — fails.
+        def spline_new(*_):
+            sp = LuaTable()
+            sp.set("segments", LuaTable())
+
+            def add(kind):
+                def f(self_, pts=None, *_a):
+                    seg = self_.get("segments")
+                    seg.set(seg.length() + 1, tbl({"kind": kind, "points": pts}))
+                return f
+
+            def query(*_a):
+                raise LuaError("PolySpline:query: embedded boundaries are outside the hyperbolic-update path")
+            sp.set("addLine", add("line"))
+            sp.set("addSpline", add("spline"))
+            sp.set("query", query)
+            return sp
+        G.set("PolySpline", tbl({"new": spline_new}))
+
+        def svg_new(path=None, *_):   # modules/eb/MFP_read_geom.cpp: same role, the file is not read here
+            sv = LuaTable()
+            sv.set("file", path)
+
+            def query(*_a):
+                raise LuaError("ReadSVG:query: embedded boundaries are outside the hyperbolic-update path")
+            sv.set("query", query)
+            return sv
+        G.set("ReadSVG", tbl({"new": svg_new}))
 
         def t_insert(t, a, b=None, *rest):
             n = t.length()
