@@ -64,7 +64,7 @@ CMFP_DEV void f3m_material_faces(double speed, double h, double& mlo, double& mh
 
 // ------------------------------------------------------------------------------------------- z direction
 template <bool HAS_BC>
-__global__ __launch_bounds__(64, 2) void k_f3m_z(Geo g, FieldParams P, const double* __restrict__ U, Ptr3 dF, double* __restrict__ DU,
+__global__ __launch_bounds__(64, 1) void k_f3m_z(Geo g, FieldParams P, const double* __restrict__ U, Ptr3 dF, double* __restrict__ DU,
                                                   double dt, FaceBC3m bc, SelF3m sel) {
     typedef FieldF<5> Phys;
     __shared__ double ring_[F3M_NR * 8 * 64 + 2 * F3M_PAD];
@@ -76,11 +76,14 @@ __global__ __launch_bounds__(64, 2) void k_f3m_z(Geo g, FieldParams P, const dou
     if (w >= sel.nwaves) return;
     const int strip = w % sel.ns;
     w /= sel.ns;
-    const int j = w % sel.nline, segi = w / sel.nline;
-    const int n0 = g.n[0], n2 = g.n[2];
+    const int j = w % sel.nline - 1, segi = w / sel.nline;  // lines j = -1 .. n1: the ring lines only leave dF_z
+    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
     const int i = strip * 56 - 4 + lane;  // dF_x of the cell comes from the x stencil of the window's centre line
     const int ic = i < n0 + 3 ? i : n0 + 3;
-    const bool upd = lane >= 4 && lane <= 59 && i < n0;
+    const bool upd = lane >= 4 && lane <= 59 && i < n0 && j >= 0 && j < n1;
+    // dF_z (sweep 1, no x stencil) is left for the cells of the block grown by one in x and y: k_f3m_yx corrects the
+    // face states of those ring cells too
+    const bool zw = (lane >= 4 && lane <= 59 && i <= n0) || (lane == 3 && i == -1) || (lane == 60 && i == n0);
     const int ka = segi * sel.seg;
     const int kb = (ka + sel.seg - 1 < n2 - 1) ? ka + sel.seg - 1 : n2 - 1;
     const double speed = P.fastest;
@@ -116,11 +119,11 @@ __global__ __launch_bounds__(64, 2) void k_f3m_z(Geo g, FieldParams P, const dou
     }
     load_plane(ka + 2, Un);
     load_dF(ka - 1, dyn);
-    double Iz_p[8], zhiC_p[8], fz_p[8];
+    double Iz_p[8], zhiC_p[8], fz_p[8], zhiT_p[8], f1z_p[8];
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         Iz_p[n] = f3m_interface(at(0, n), at(1, n), at(2, n), at(3, n), at(4, n), at(5, n));
-        zhiC_p[n] = fz_p[n] = 0.0;
+        zhiC_p[n] = fz_p[n] = zhiT_p[n] = f1z_p[n] = 0.0;
     }
 
     for (int k = ka - 1; k <= kb + 1; ++k) {
@@ -171,14 +174,36 @@ __global__ __launch_bounds__(64, 2) void k_f3m_z(Geo g, FieldParams P, const dou
             zhi[n] = Iz;
             Iz_p[n] = Iz;
             trace_faces(speed, hz, centre, zlo[n], zhi[n]);
+        }
+        zlo[8] = zlo[9] = mlo;
+        zhi[8] = zhi[9] = mhi;
+        {
+            // Riemann sweep 1 on the low z-face with the traced, uncorrected states: dF_z of plane k - 1 for k_f3m_yx
+            // (the first plane of a segment solves on the zero-initialised carried state; nothing of it is stored)
+            double L[10], f1z[10];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) L[n] = zhiT_p[n];
+            L[8] = L[9] = mhi;
+            Phys::riemann(P, 2, L, zlo, f1z);
+            if (k > ka && zw) {
+                const long c = col + (long)(k - 1) * sz;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) dF.p[2][c + n * g.sc] = f1z_p[n] - f1z[n];
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                zhiT_p[n] = zhi[n];
+                f1z_p[n] = f1z[n];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
             // z faces: corrected with dF_x then dF_y
             zhi[n] += hx * dFx[n];
             zlo[n] += hx * dFx[n];
             zhi[n] += hy * dFy[n];
             zlo[n] += hy * dFy[n];
         }
-        zlo[8] = zlo[9] = mlo;
-        zhi[8] = zhi[9] = mhi;
         double fz[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (k >= ka) {
             double L[10];
@@ -635,8 +660,7 @@ static SelF3m f3m_select(int ns, int nline, int nmarch, int slots) {
 // Pass 1 of the 3-D field update on the marching kernels: dF_y and dF_z of every cell (dF_x is recomputed by pass 2)
 static void f3m_pass1(const Geo& g, const StatePhys& sp, const double* Uin, const Ptr3& dF, double dt, hipStream_t st) {
     const dim3 block(64);
-    const SelF3m a = f3m_select((g.n[0] + 2 + 63) / 64, g.n[1] + 2, g.n[2], f3m_slots(6));
-    hipLaunchKernelGGL(k_f3m_z1, dim3(((a.nwaves + 7) / 8) * 8), block, 0, st, g, sp.fp, Uin, dF.p[2], dt, a);
+    // (dF_z: left by k_f3m_z, which marches along z anyway; k_f3m_z1 remains as its stand-alone form)
     const SelF3m b = f3m_select((g.n[0] + 2 + 63) / 64, g.n[2] + 2, g.n[1], f3m_slots(6));
     hipLaunchKernelGGL(k_f3m_y1, dim3(((b.nwaves + 7) / 8) * 8), block, 0, st, g, sp.fp, Uin, dF.p[1], dt, b);
 }
@@ -663,7 +687,7 @@ int ctu_field3d_march(const Geo& g, const StatePhys& sp, const double* Uin, doub
             }
         }
     const dim3 block(64);
-    const SelF3m a = f3m_select((g.n[0] + 55) / 56, g.n[1], g.n[2], f3m_slots(6));
+    const SelF3m a = f3m_select((g.n[0] + 55) / 56, g.n[1] + 2, g.n[2], f3m_slots(4));
     const dim3 ga(((a.nwaves + 7) / 8) * 8);
     if (has_bc)
         hipLaunchKernelGGL((k_f3m_z<true>), ga, block, 0, st, g, sp.fp, Uin, dF, DU, dt, bc, a);
