@@ -267,33 +267,35 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
 #pragma unroll
             for (int n = 0; n < 8; ++n) V[n] = Uin[c + n * g.sc];
         };
-        auto load_dF = [&](int row, double* b, double* cz) {
+        auto load_dF = [&](int row, double* cz) {
             const long c = col + (long)row * sy;
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                b[n] = dF.p[1][c + n * g.sc];
-                cz[n] = dF.p[2][c + n * g.sc];
-            }
+            for (int n = 0; n < 8; ++n) cz[n] = dF.p[2][c + n * g.sc];
         };
         auto slot_of = [&](int row) { return (row - row0) % F3M_NR; };
         auto at = [&](int slot, int n, int l) -> double& { return ring[(slot * 8 + n) * 64 + l]; };
 
-        double Un[8], dyn[8], dzn[8], gzn[8];
+        double Un[8], dzn[8], gzn[8];
         for (int s = 0; s < F3M_NR; ++s) {
             load_row(row0 + s, Un);
 #pragma unroll
             for (int n = 0; n < 8; ++n) at(s, n, lane) = Un[n];
         }
         load_row(ja + 2, Un);
-        load_dF(ja - 1, dyn, dzn);
+        load_dF(ja - 1, dzn);
 #pragma unroll
         for (int n = 0; n < 8; ++n) gzn[n] = 0.0;
-        double Iy_p[8], yhiC_p[8], fy_p[8], X_p[8], gz[8];
+        // carried from row r - 1: the traced x-face states (corrected one iteration later, when dF_y of their row is
+        // known: dF_y(r - 1) = F1_y(r - 1) - F1_y(r) is recomputed here, not read), dF_z of that row, the traced
+        // uncorrected high y-face and F1_y on the low y-face (sweep 1), the corrected high y-face and F'_y (sweep 2)
+        double Iy_p[8], yhiC_p[8], fy_p[8], gz[8], xlo_p[10], xhi_p[10], dFz_p[8], yhiT_p[8], f1y_p[8];
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
             Iy_p[n] = f3m_interface(at(0, n, lane), at(1, n, lane), at(2, n, lane), at(3, n, lane), at(4, n, lane), at(5, n, lane));
-            yhiC_p[n] = fy_p[n] = X_p[n] = gz[n] = 0.0;
+            yhiC_p[n] = fy_p[n] = gz[n] = xlo_p[n] = xhi_p[n] = dFz_p[n] = yhiT_p[n] = f1y_p[n] = 0.0;
         }
+        xlo_p[8] = xlo_p[9] = mlo[0];
+        xhi_p[8] = xhi_p[9] = mhi[0];
         double sp_cur[SRC > 0 ? SRC : 1][5], sp_nxt[SRC > 0 ? SRC : 1][5];
 #pragma unroll
         for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s)
@@ -301,21 +303,20 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
             for (int n = 0; n < 5; ++n) sp_cur[s][n] = sp_nxt[s][n] = 1.0;
 
         for (int r = ja - 1; r <= jb + 1; ++r) {
-            double dFx[8], dFy[8], dFz[8];
+            double dFx[8], dFy_p[8], dFz[8];
             __syncthreads();  // every lane has finished reading the slot that is overwritten
             {
                 const int sn = slot_of(r + 3);
 #pragma unroll
                 for (int n = 0; n < 8; ++n) {
                     at(sn, n, lane) = Un[n];
-                    dFy[n] = dyn[n];
                     dFz[n] = dzn[n];
                     gz[n] = gzn[n];  // G_z of row r - 1 (requested in the previous iteration)
                 }
                 const int rn = r + 4 < jb + 4 ? r + 4 : jb + 4;
                 load_row(rn, Un);
                 const int rd = r + 1 < jb + 1 ? r + 1 : jb + 1;
-                load_dF(rd, dyn, dzn);
+                load_dF(rd, dzn);
                 if (upd && r >= ja && r <= jb) {
                     const long c = col + (long)r * sy;
 #pragma unroll
@@ -359,13 +360,31 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
                     yhi[n] = Iy;
                     Iy_p[n] = Iy;
                     trace_faces(speed, hy, centre, ylo[n], yhi[n]);
+                }
+                ylo[8] = ylo[9] = mlo[1];
+                yhi[8] = yhi[9] = mhi[1];
+                {
+                    // Riemann sweep 1 on the low y-face with the traced, uncorrected states: dF_y of row r - 1 (the
+                    // first rows of a segment solve on the zero-initialised carried state; nothing of it is stored)
+                    double L[10], f1y[10];
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) L[n] = yhiT_p[n];
+                    L[8] = L[9] = mhi[1];
+                    Phys::riemann(P, 1, L, ylo, f1y);
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        dFy_p[n] = f1y_p[n] - f1y[n];
+                        yhiT_p[n] = yhi[n];
+                        f1y_p[n] = f1y[n];
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
                     yhi[n] += hz * dFz[n];
                     ylo[n] += hz * dFz[n];
                     yhi[n] += hx * dFx[n];
                     ylo[n] += hx * dFx[n];
                 }
-                ylo[8] = ylo[9] = mlo[1];
-                yhi[8] = yhi[9] = mhi[1];
                 if (r >= ja) {
                     double L[10];
 #pragma unroll
@@ -378,7 +397,31 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
 #pragma unroll
                 for (int n = 0; n < 8; ++n) yhiC_p[n] = yhi[n];
             }
-            // ---- divergence of row r - 1 and update (its x part was left by the previous iteration)
+            // ---- x faces of row r - 1: corrected with dF_y then dF_z; BCs; sweep 2; x part of the divergence
+            double X_p[8];
+            {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    xhi_p[n] += hy * dFy_p[n];
+                    xlo_p[n] += hy * dFy_p[n];
+                    xhi_p[n] += hz * dFz_p[n];
+                    xlo_p[n] += hz * dFz_p[n];
+                }
+                double L[10], fx[10];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) L[n] = lane_left(xhi_p[n]);
+                L[8] = L[9] = mhi[0];
+                if (HAS_BC && bc.touch[0][0] && i == 0) f3m_bc(bc.rule[0][0], true, L, xlo_p);
+                if (HAS_BC && bc.touch[0][1] && i == n0) f3m_bc(bc.rule[0][1], false, L, xlo_p);
+                Phys::riemann(P, 0, L, xlo_p, fx);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    double du = 0.0;
+                    du += dtdx * (fx[n] - lane_right(fx[n]));
+                    X_p[n] = du;
+                }
+            }
+            // ---- divergence of row r - 1 and update
             if (r > ja) {
                 double Unew[10];
 #pragma unroll
@@ -397,30 +440,13 @@ __global__ __launch_bounds__(64, 1) void k_f3m_yx(Geo g, FieldParams P, const do
                 }
             }
 #pragma unroll
-            for (int n = 0; n < 8; ++n) fy_p[n] = fy[n];
-            // ---- x faces of row r: corrected with dF_y then dF_z; BCs; sweep 2; x part of the divergence
-            {
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    xhi[n] += hy * dFy[n];
-                    xlo[n] += hy * dFy[n];
-                    xhi[n] += hz * dFz[n];
-                    xlo[n] += hz * dFz[n];
-                }
-                double L[10], fx[10];
-#pragma unroll
-                for (int n = 0; n < 8; ++n) L[n] = lane_left(xhi[n]);
-                L[8] = L[9] = mhi[0];
-                if (HAS_BC && bc.touch[0][0] && i == 0) f3m_bc(bc.rule[0][0], true, L, xlo);
-                if (HAS_BC && bc.touch[0][1] && i == n0) f3m_bc(bc.rule[0][1], false, L, xlo);
-                Phys::riemann(P, 0, L, xlo, fx);
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    double du = 0.0;
-                    du += dtdx * (fx[n] - lane_right(fx[n]));
-                    X_p[n] = du;
-                }
+            for (int n = 0; n < 8; ++n) {
+                fy_p[n] = fy[n];
+                xlo_p[n] = xlo[n];  // traced, uncorrected: corrected in the next iteration
+                xhi_p[n] = xhi[n];
+                dFz_p[n] = dFz[n];
             }
+            xlo_p[8] = xlo_p[9] = mlo[0];
             if constexpr (SRC > 0) {
 #pragma unroll
                 for (int s = 0; s < SRC; ++s)
