@@ -321,8 +321,11 @@ bool ctu_march_interior(const Geo& g, const StatePhys& sp, int do_ctu, IBox& box
 
 // Two hydro states in one launch (see MarchStates).  Returns 0 — nothing launched — unless both are covered
 // by ctu_march with the same kernel instance and the same domain-face rules; Uin[0] == nullptr probes.
+int ctu_march3d2(const Geo& g, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
+                 const int touches[3][2], int* err, unsigned long long* const red[2], hipStream_t st);
 int ctu_march2(const Geo& g, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
                const int touches[3][2], int* err, unsigned long long* const red[2], int part, hipStream_t st) {
+    if (g.dim == 3) return part == 0 ? ctu_march3d2(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, st) : 0;
     const StatePhys &a = *sp[0], &b = *sp[1];
     if (g.dim != 2 || a.kind != 0 || b.kind != 0 || !do_ctu) return 0;
     if (a.recon != b.recon || a.flux != b.flux || a.nc != b.nc || (red[0] == nullptr) != (red[1] == nullptr)) return 0;

@@ -19,6 +19,8 @@
 // Against the gather kernels (mfp_gather.hip), which recompute the reconstruction of both cells of every
 // face in both sweeps and move two sets of face fluxes through HBM, every cell is reconstructed once
 // and only U is read and written.  Same device functions: STRICT results are bit-identical.
+#include <cstring>
+
 #include "mfp_march.h"
 
 namespace CMFP_NS {
@@ -44,10 +46,18 @@ struct Sel3 {
     int gx, gy, nseg, seg, n;  // tiles in x and y, z-segments, planes per segment, workgroups
 };
 
+// the states one launch updates: one, or two species of the same physics (mfp_march.hip: MarchStates)
+template <class Phys>
+struct March3States {
+    int n;
+    typename Phys::Params P[2];
+    const double* Uin[2];
+    double* Uout[2];
+    unsigned long long* red[2];
+};
+
 template <class Phys, bool HAS_BC, bool REDUCE>
-__global__ __launch_bounds__(256, 2) void k_ctu3d(Geo g, typename Phys::Params P, const double* __restrict__ Uin,
-                                                   double* __restrict__ Uout, double dt, FaceBC3m bc, int* err, Sel3 sel,
-                                                   unsigned long long* red) {
+__global__ __launch_bounds__(256, 2) void k_ctu3d(Geo g, March3States<Phys> S, double dt, FaceBC3m bc, int* err, Sel3 sel) {
     constexpr int RECON = Phys::RECON;
     static_assert(ReconTraits<RECON>::SL == 3 && Phys::IS_HYDRO, "three-point hydro reconstructions");
     constexpr int BX = 16, BY = 16, TX = BX - 2, TY = BY - 2, PX = BX + 2, PY = BY + 2, C = BX * BY, NP = PX * PY;
@@ -60,9 +70,16 @@ __global__ __launch_bounds__(256, 2) void k_ctu3d(Geo g, typename Phys::Params P
 
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * BX + tx;
     // XCD-aware order (see mfp_fused.hip): a contiguous band of workgroups per XCD
-    const int per = (sel.n + 7) >> 3;
-    const int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (wg >= sel.n) return;
+    const int total = sel.n * S.n;
+    const int per = (total + 7) >> 3;
+    int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (wg >= total) return;
+    const int which = wg >= sel.n ? 1 : 0;  // workgroup-uniform: the state this workgroup updates
+    wg -= which * sel.n;
+    const typename Phys::Params P = S.P[which];
+    const double* __restrict__ Uin = S.Uin[which];
+    double* __restrict__ Uout = S.Uout[which];
+    unsigned long long* red = S.red[which];
     const int tiles = sel.gx * sel.gy;
     const int segi = wg / tiles, tile = wg - segi * tiles;
     const int tiy = tile / sel.gx, tix = tile - tiy * sel.gx;
@@ -346,10 +363,20 @@ __global__ __launch_bounds__(256, 2) void k_ctu3d(Geo g, typename Phys::Params P
 }
 
 template <class Phys>
-static int launch3d(const Geo& g, const typename Phys::Params& P, const StatePhys& sp, const double* Uin, double* Uout, double dt,
-                    const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
+static int launch3d(const Geo& g, int ns, const StatePhys* const sps[2], const double* const Uins[2], double* const Uouts[2], double dt,
+                    const int touches[3][2], int* err, unsigned long long* const reds[2], hipStream_t st) {
     if (g.ng[0] < 2 || g.ng[1] < 2 || g.ng[2] < 2) return 0;
-    if (!Uin) return 1;  // coverage probe
+    if (!Uins[0]) return 1;  // coverage probe
+    const StatePhys& sp = *sps[0];
+    March3States<Phys> S;
+    std::memset(&S, 0, sizeof(S));
+    S.n = ns;
+    for (int k = 0; k < ns; ++k) {
+        S.P[k] = sps[k]->hp;
+        S.Uin[k] = Uins[k];
+        S.Uout[k] = Uouts[k];
+        S.red[k] = reds[k];
+    }
     Sel3 sel;
     sel.gx = (g.n[0] + 13) / 14;
     sel.gy = (g.n[1] + 13) / 14;
@@ -357,7 +384,9 @@ static int launch3d(const Geo& g, const typename Phys::Params& P, const StatePhy
     // 32-plane segments are best, 4.8 ms for two states; one segment per tile, 361 workgroups: 6.6 ms),
     // at least 12 planes each (96^3: 12-plane segments beat 16 by 8 %; 128^3: no difference)
     const int tiles = sel.gx * sel.gy;
-    int nseg = (2 * wave_slots() + tiles - 1) / tiles;  // wave_slots() / 4 workgroups are resident at 2 waves per SIMD: eight rounds
+    // wave_slots() / 4 workgroups are resident at 2 waves per SIMD: eight rounds per launch (two states in one
+    // launch: half as many, longer segments - 256^3: 43 planes against 22, both species 4.20 -> 4.08 ms)
+    int nseg = (2 * wave_slots() / ns + tiles - 1) / tiles;
     if (nseg < 1) nseg = 1;
     int seg = (g.n[2] + nseg - 1) / nseg;
     if (seg < 12) seg = 12;
@@ -378,10 +407,9 @@ static int launch3d(const Geo& g, const typename Phys::Params& P, const StatePhy
                 bc.rule[d][s][n] = (code == 2 || code == 4 || code == 1) ? FILL_EVEN : (code == -1 ? FILL_ODD : FILL_SKIP);
             }
         }
-    const dim3 grid(((sel.n + 7) / 8) * 8), block(16, 16);
-#define CMFP_LAUNCH(BC, RED) \
-    hipLaunchKernelGGL((k_ctu3d<Phys, BC, RED>), grid, block, 0, st, g, P, Uin, Uout, dt, bc, err, sel, red)
-    if (red) {
+    const dim3 grid(((sel.n * ns + 7) / 8) * 8), block(16, 16);
+#define CMFP_LAUNCH(BC, RED) hipLaunchKernelGGL((k_ctu3d<Phys, BC, RED>), grid, block, 0, st, g, S, dt, bc, err, sel)
+    if (reds[0]) {
         if (has_bc) CMFP_LAUNCH(true, true); else CMFP_LAUNCH(false, true);
     } else {
         if (has_bc) CMFP_LAUNCH(true, false); else CMFP_LAUNCH(false, false);
@@ -395,8 +423,28 @@ static int launch3d(const Geo& g, const typename Phys::Params& P, const StatePhy
 int ctu_march3d(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
                 const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
     if (g.dim != 3 || sp.kind != 0 || !do_ctu || sp.hp.nt) return 0;
+    const StatePhys* const sps[2] = {&sp, nullptr};
+    const double* const in[2] = {Uin, nullptr};
+    double* const out[2] = {Uout, nullptr};
+    unsigned long long* const reds[2] = {red, nullptr};
 #define HY(R, F) \
-    if (sp.recon == R && sp.flux == F) return launch3d<HydroF<R, F>>(g, sp.hp, sp, Uin, Uout, dt, touches, err, red, st);
+    if (sp.recon == R && sp.flux == F) return launch3d<HydroF<R, F>>(g, 1, sps, in, out, dt, touches, err, reds, st);
+    HY(1, 0) HY(1, 1) HY(2, 0) HY(2, 1) HY(3, 0) HY(4, 0)
+#undef HY
+    return 0;
+}
+
+// two 3-D hydro states of the same physics in one launch (as ctu_march2 in 2-D); 0: nothing launched
+int ctu_march3d2(const Geo& g, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
+                 const int touches[3][2], int* err, unsigned long long* const red[2], hipStream_t st) {
+    const StatePhys &a = *sp[0], &b = *sp[1];
+    if (g.dim != 3 || a.kind != 0 || b.kind != 0 || !do_ctu || a.hp.nt || b.hp.nt) return 0;
+    if (a.recon != b.recon || a.flux != b.flux || (red[0] == nullptr) != (red[1] == nullptr)) return 0;
+    if (std::memcmp(a.bc, b.bc, sizeof(a.bc)) != 0) return 0;
+    static const bool off = std::getenv("CMFP_MARCH_PAIR") && std::atoi(std::getenv("CMFP_MARCH_PAIR")) == 0;
+    if (off) return 0;
+#define HY(R, F) \
+    if (a.recon == R && a.flux == F) return launch3d<HydroF<R, F>>(g, 2, sp, Uin, Uout, dt, touches, err, red, st);
     HY(1, 0) HY(1, 1) HY(2, 0) HY(2, 1) HY(3, 0) HY(4, 0)
 #undef HY
     return 0;
