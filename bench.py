@@ -290,8 +290,8 @@ def main():
             per = prof[1][0] / tsteps if prof[1][0] else 1
             epilogue = prof[2][0] == tsteps
             froof = roof_of(1, 320 if epilogue else 160,
-                            "3-D field CTU update, the four marching launches of one step (k_f3m_y1, k_f3m_z1, k_f3m_z, k_f3m_yx)" + (" + Strang source stage C of both species" if epilogue else ""),
-                            per, [("k_f3m_y1",), ("k_f3m_z1",), ("k_f3m_z<",), ("k_f3m_yx<",)])
+                            "3-D field CTU update, the three marching launches of one step (k_f3m_y1, k_f3m_z, k_f3m_yx)" + (" + Strang source stage C of both species" if epilogue else ""),
+                            per, [("k_f3m_y1",), ("k_f3m_z<",), ("k_f3m_yx<",)])
         else:
             hname = ("k_ctu2d<HydroF<minmod,HLLC>> (LDS-tiled fused CTU update of one hydro state)" if args.tiled_hydro
                      else "k_ctu_march<HydroF<minmod,HLLC>> (wave-marching fused CTU update of the hydro states: %d per launch)"
