@@ -1,4 +1,4 @@
-"""world_size 2 and 4 on CPU (gloo): the block decomposition, neighbour map,
+"""world_size 2, 4 and 8 on CPU (gloo): the block decomposition, neighbour map,
 message ordering and ghost-slab conventions of MFP._exchange, with the three
 device hooks (count / pack / unpack) replaced by a numpy emulation of the
 pack kernel's conventions.  Every rank must end up with exactly the ghost cells
@@ -130,7 +130,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("batched", [False, True])
-@pytest.mark.parametrize("world,periodic", [(2, [1, 1, 0]), (4, [1, 1, 0]), (2, [1, 0, 0]), (4, [0, 1, 0])])
+@pytest.mark.parametrize("world,periodic", [(2, [1, 1, 0]), (4, [1, 1, 0]), (2, [1, 0, 0]), (4, [0, 1, 0]),
+                                            (8, [1, 1, 0]), (8, [1, 0, 0])])   # 8 = the 2 x 4 grid of the N = 8 scaling run
 def test_halo_exchange_protocol(world, periodic, batched):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()

@@ -27,7 +27,7 @@ def _run(nranks, extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--rehearse",
            "--no-cpu-baseline", "--reps", "2"] + extra
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]        # rank 0 prints ONE JSON line
@@ -39,6 +39,9 @@ def _run(nranks, extra):
     (4, ["--workload", "ot2f_2d", "--cells", "256", "--steps", "2", "--warmup", "1"], 256 * 256),
     (2, ["--workload", "gem_2d", "--cells", "512", "--steps", "3", "--warmup", "1"], 512 * 256),
     (2, ["--workload", "rmi_3d", "--cells", "64", "--steps", "2", "--warmup", "1"], 64 ** 3),
+    # the rank count of the last leg of the scaling run (process grids 2 x 4 and 2 x 2 x 2)
+    (8, ["--workload", "ot2f_2d", "--cells", "256", "--steps", "2", "--warmup", "1"], 256 * 256),
+    (8, ["--workload", "rmi_3d", "--cells", "32", "--steps", "2", "--warmup", "1"], 32 ** 3),
 ])
 def test_bench_n_rank_path(nranks, extra, cells):
     out = _run(nranks, extra)

@@ -51,6 +51,8 @@ def _cfg(which):
         return inflow_cfg(32, 16)
     if which == "gem":
         return problems.gem_reconnection_2d(32, 32)
+    if which == "gem64":        # 2 x 4 blocks of 32 x 16 with the conducting walls on the outer ranks in y
+        return problems.gem_reconnection_2d(64, 64)
     if which.startswith("rand"):   # a drawn option set (tests/test_gpu_random.py) on a grid every process grid divides
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from test_gpu_random import draw
@@ -73,7 +75,9 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,which,batched", [(2, "ot", True), (4, "ot", True), (4, "ot", False), (4, "gem", True), (4, "ot96", True), (2, "ot96", False), (2, "ot512", True), (4, "ot512", True),
-                                                 (4, "rmi3d", True), (4, "rmi3d24", True), (2, "rmi3d24", False), (4, "inflow", True), (2, "inflow", False)] +
+                                                 (4, "rmi3d", True), (4, "rmi3d24", True), (2, "rmi3d24", False), (4, "inflow", True), (2, "inflow", False),
+                                                 # eight ranks = the 2 x 4 (2-D) and 2 x 2 x 2 (3-D) process grids of the N = 8 scaling run
+                                                 (8, "ot512", True), (8, "ot96", True), (8, "gem64", True), (8, "rmi3d24", True)] +
                                                 [(2 + 2 * (k % 2), f"rand{k}", k % 3 != 0) for k in range(10)])
 def test_decomposed_run_equals_single_rank(world, which, batched):
     import torch.multiprocessing as mp
@@ -86,7 +90,7 @@ def test_decomposed_run_equals_single_rank(world, which, batched):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(90)
+        p.join(150)
     hung = [p for p in procs if p.is_alive()]
     for p in hung:          # a rank that is still waiting for a message: end it rather than block the suite
         p.terminate()
