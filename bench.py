@@ -213,6 +213,7 @@ def main():
         m.init_data()
         m.run(warmup)
         fused = m.last_advance_path()
+        fusion = m.last_source_fusion()   # bit 0: source stage A inside the CTU kernels, bit 1: stage C inside the field's
         sync()
         m.profile_enable(True)
         for s in range(4):
@@ -245,6 +246,8 @@ def main():
                "kernel_ms_per_step": {"ctu_hydro": prof[0][1] / tsteps, "ctu_field": prof[1][1] / tsteps,
                                       "source_rk2": prof[2][1] / tsteps, "ghost_fill": prof[3][1] / tsteps},
                "fused_path": fused, "fp_mode": fp,
+               "source_stages": {"A": "prologue of the CTU kernels" if fusion & 1 else "own launch",
+                                 "C": "epilogue of the field kernel" if fusion & 2 else "own launch"},
                "workload": f"{workload} {'x'.join(str(v) for v in blk)} per GPU ({WORKLOAD_NOTE[workload]})",
                "process_grid": grid[:dim], "global_cells": list(P.n_cell[:dim]), "time_integration": P.scheme, "cfl": P.cfl}
         if world > 1:
@@ -288,19 +291,21 @@ def main():
         if dim == 3:
             hroof = roof_of(0, 80, "k_ctu3d<HydroF<minmod,HLLC>> (z-marching fused CTU update of one hydro state)", 1, [("k_ctu3d",)], n_hydro)
             per = prof[1][0] / tsteps if prof[1][0] else 1
-            epilogue = prof[2][0] == tsteps
+            epilogue = bool(fusion & 2)
             froof = roof_of(1, 320 if epilogue else 160,
                             "3-D field CTU update, the three marching launches of one step (k_f3m_y1, k_f3m_z, k_f3m_yx)" + (" + Strang source stage C of both species" if epilogue else ""),
                             per, [("k_f3m_y1",), ("k_f3m_z<",), ("k_f3m_yx<",)])
         else:
             hname = ("k_ctu2d<HydroF<minmod,HLLC>> (LDS-tiled fused CTU update of one hydro state)" if args.tiled_hydro
-                     else "k_ctu_march<HydroF<minmod,HLLC>> (wave-marching fused CTU update of the hydro states: %d per launch)"
-                     % max(1, round(n_hydro * tsteps / max(1, prof[0][0]))))
+                     else "k_ctu_march<HydroF<minmod,HLLC>> (wave-marching fused CTU update of the hydro states: %d per launch%s)"
+                     % (max(1, round(n_hydro * tsteps / max(1, prof[0][0]))),
+                        "; Strang source stage A applied to the rows as they are loaded" if fusion & 1 else ""))
             hroof = roof_of(0, 80, hname, 1, [("k_ctu2d<fast::HydroF",) if args.tiled_hydro else ("k_ctu_march",)], n_hydro)
             froof = None
             if prof[1][0] == tsteps:   # one field launch per step (no interior / frame split)
-                epilogue = prof[2][0] == tsteps     # one separate source launch per step: stage C is in the field kernel
-                fname = ("k_fld_march<SRC=2> (wave-marching fused CTU update of the vacuum field state + Strang source stage C of both species)"
+                epilogue = bool(fusion & 2)     # stage C is in the field kernel
+                fname = ("k_fld_march<SRC=2> (wave-marching fused CTU update of the vacuum field state + Strang source stage C of both species"
+                         + (", stage A applied to the rows as they enter the window)" if fusion & 1 else ")")
                          if epilogue else "k_fld_march (wave-marching fused CTU update of the vacuum field state)")
                 froof = roof_of(1, 320 if epilogue else 160, fname, 1, [("k_fld_march",)])
         roof, other = hroof, froof
@@ -327,14 +332,14 @@ def main():
                        "time_integration": main_res["time_integration"], "cfl": main_res["cfl"]},
             "hbm_roofline_frac_whole_step": main_res["hbm_roofline_frac_whole_step"],
             "roofline": main_res["roofline"], "roofline_other": main_res["roofline_other"],
-            "kernel_ms_per_step": main_res["kernel_ms_per_step"],
+            "kernel_ms_per_step": main_res["kernel_ms_per_step"], "source_stages": main_res["source_stages"],
         }
         if "host_ms_per_step" in main_res:
             out["host_ms_per_step"] = main_res["host_ms_per_step"]
     # ---- extra legs: single GPU only (they are not part of the scaling contract)
     if world == 1 and not args.no_extras:
         keep = ("value", "ms_per_step", "rep_ms_per_step", "hbm_roofline_frac_whole_step", "kernel_ms_per_step", "roofline",
-                "roofline_other", "workload", "fp_mode")
+                "roofline_other", "workload", "fp_mode", "source_stages")
         other_fp = "strict" if args.fp == "fast" else "fast"
         r = measure(args.workload, args.n, other_fp, max(5, args.steps // 2), 2, 3, copy_gbs)
         out[other_fp] = {k: r[k] for k in keep if k in r}

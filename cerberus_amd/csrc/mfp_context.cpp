@@ -63,6 +63,9 @@ struct StateRT {
     // field: the materials check (mu == ep == 1 everywhere) has been made for the data now in new_data;
     // the ping-pong partner holds mu, ep too (the vacuum kernel neither reads nor rewrites them)
     bool vac_known = false, alt_mat = false;
+    // ghost layers the fills and the halo exchange keep current: the state's own stencil reach (sp.ng), or the
+    // field's where the field's CTU kernel applies source stage A to the species it reads (the prologue)
+    int fill_ng = 0;
 };
 
 }  // namespace
@@ -88,6 +91,9 @@ struct cmfp_context {
     void* exchange_user = nullptr;
     int exchange_batched = 0;
     int src_epilogue = 1;      // Strang stage C inside the field's CTU kernel where that applies (CMFP_SRC_EPILOGUE=0: never)
+    int src_prologue = 1;      // Strang stage A inside the 2-D marching CTU kernels where that applies (CMFP_SRC_PROLOGUE=0: never)
+    int last_prologue = 0;     // the last fused step ran stage A as the CTU kernels' prologue
+    int last_epilogue = 0;     // ... and stage C as the field kernel's epilogue
     int overlap = 1;           // 1: interior flux tiles overlap the halo exchange where the block is split; 2: always split the launches
     hipStream_t stream2 = nullptr;  // interior tiles run here while ghost cells are in flight on `stream`
     hipEvent_t ev_src = nullptr, ev_int = nullptr, ev_hyd = nullptr;  // one callback per dimension for all states (state = CMFP_ALL_STATES)
@@ -216,12 +222,12 @@ int fill_patch(cmfp_context* c, int si) {
         if (!c->split[d]) {
             for (int side = 0; side < 2; ++side) {
                 FillRules r = c->geom.is_periodic[d] ? wrap_rules(s) : bc_rules(s, d, side);
-                c->L->fill_dim(g, s.sp.nc, s.sp.ng, s.new_data, d, side, r, c->stream);
+                c->L->fill_dim(g, s.sp.nc, s.fill_ng, s.new_data, d, side, r, c->stream);
             }
         } else {
             for (int side = 0; side < 2; ++side)
                 if (c->touches[d][side])
-                    c->L->fill_dim(g, s.sp.nc, s.sp.ng, s.new_data, d, side, bc_rules(s, d, side), c->stream);
+                    c->L->fill_dim(g, s.sp.nc, s.fill_ng, s.new_data, d, side, bc_rules(s, d, side), c->stream);
             if (!c->exchange)
                 return fail(c, CMFP_ERR_INVALID, "domain is split along a dimension but no exchange callback is set");
             int r = c->exchange(c->exchange_user, c, si, d);
@@ -250,7 +256,7 @@ int fill_patch_many(cmfp_context* c, const std::vector<int>& list) {
             FillJob& f = J.j[J.n];
             f.A = s.new_data;
             f.nc = s.sp.nc;
-            f.ngs = s.sp.ng;
+            f.ngs = s.fill_ng;
             for (int side = 0; side < 2; ++side) {
                 f.on[side] = !c->split[d] || c->touches[d][side];
                 f.rules[side] = (!c->split[d] && c->geom.is_periodic[d]) ? wrap_rules(s) : bc_rules(s, d, side);
@@ -686,8 +692,6 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     for (size_t q = 0; q < list.size() && overlap; ++q)
         overlap = tiled[list[q]] && c->L->ctu_fused(c->g, c->states[list[q]].sp, nullptr, nullptr, ctu_flag[q], dt, c->touches,
                                                     nullptr, nullptr, 1 | tile_flag, c->stream);
-    bool src_split = false;
-    IBox src_inner;
     if ((overlap || (src >= 0 && split_any && c->overlap != 0)) && !c->stream2) {
         if (c->no_alloc)
             return fail(c, CMFP_ERR_INVALID, "cmfp_advance_steps_static: the overlap stream does not exist yet; run one cmfp_advance first");
@@ -707,45 +711,6 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         }
     }
     if (reserve_only) return 1;  // cmfp_create: everything this kernel selection allocates now exists
-    if (src >= 0) {
-        SourceArgs a = source_args(c, c->actions[src], true);
-        if (coll >= 0) a.coll = coll_args(c, c->actions[coll]);
-        IBox inner;
-        bool has_inner = !overlap && split_any && c->overlap != 0;
-        for (int d = 0; d < 3; ++d) {
-            const int w = d < c->g.dim ? c->g.ng[d] : 0;
-            inner.lo[d] = w;
-            inner.hi[d] = c->g.n[d] - 1 - w;
-            has_inner = has_inner && (d >= c->g.dim || inner.hi[d] >= inner.lo[d]);
-        }
-        if (has_inner) {
-            // frame: slabs peeled off dimension by dimension (disjoint), on the main stream
-            IBox rest;
-            for (int d = 0; d < 3; ++d) {
-                rest.lo[d] = 0;
-                rest.hi[d] = c->g.n[d] - 1;
-            }
-            {
-                ProfScope prof(c, CMFP_PROF_SOURCE);
-                for (int d = c->g.dim - 1; d >= 0; --d) {
-                    IBox lo_slab = rest, hi_slab = rest;
-                    lo_slab.hi[d] = inner.lo[d] - 1;
-                    hi_slab.lo[d] = inner.hi[d] + 1;
-                    if (!c->L->source_fused_box(c->g, a, 0.5 * dt, lo_slab, c->stream)) return 0;
-                    if (!c->L->source_fused_box(c->g, a, 0.5 * dt, hi_slab, c->stream)) return 0;
-                    rest.lo[d] = inner.lo[d];
-                    rest.hi[d] = inner.hi[d];
-                }
-            }
-            HIPCHK(c, hipEventRecord(c->ev_src, c->stream));  // everything of the previous step, and the frame
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_src, 0));
-            src_split = true;
-            src_inner = inner;
-        } else {
-            ProfScope prof(c, CMFP_PROF_SOURCE);
-            if (!c->L->source_fused(c->g, a, 0.5 * dt, 0, c->stream)) return 0;
-        }
-    }
     // Strang stage C as the epilogue of the field's CTU kernel (the last launch of the step): explicit
     // plasma5 / Lorentz over species that are all CTU states, 2-D tiled field kernel
     int epi_q = -1;
@@ -788,6 +753,87 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
                                                c->stream) != 0;
         }
         if (!ok) epi_q = -1;
+    }
+    // Strang stage A as the prologue of the marching kernels (mfp_source.h): FAST arithmetic, 2-D, the two species
+    // of an explicit plasma5 / Lorentz action in one paired hydro launch, the field on the marching vacuum kernel
+    // with stage C as its epilogue, no physical face on this block.  Then no kernel of the step rewrites a state in
+    // place: the ghost fills and the exchange move the values of the previous step, the CTU kernels apply stage A
+    // to what they load.
+    SourcePro pro;
+    std::memset(&pro, 0, sizeof(pro));
+    if (epi_q >= 0 && c->src_prologue && c->params.fp_mode == CMFP_FP_FAST && c->g.dim == 2 && epi.ns == 2 && !tile_flag &&
+        list.size() == 3) {
+        const cmfp_action_desc& SA = c->actions[src];
+        size_t qs[2] = {0, 0};
+        int found = 0;
+        for (size_t q = 0; q < list.size(); ++q)
+            if ((int)q != epi_q) {
+                if (found < 2) qs[found] = q;
+                ++found;
+            }
+        const StateRT &sa = c->states[list[qs[0]]], &sb = c->states[list[qs[1]]], &sf = c->states[list[epi_q]];
+        bool ok = found == 2 && tiled[list[qs[0]]] && tiled[list[qs[1]]] && ctu_flag[qs[0]] == ctu_flag[qs[1]];
+        ok = ok && sa.fill_ng >= sf.sp.ng && sb.fill_ng >= sf.sp.ng;  // the field's kernel reads the species over its own reach
+        pro.on = 1;
+        pro.fld = sf.new_data;
+        pro.Larmor = epi.a.Larmor, pro.Debye = epi.a.Debye, pro.lightspeed = epi.a.lightspeed;
+        pro.c_h = epi.a.c_h, pro.div_damp = epi.a.div_damp, pro.lorentz_only = epi.a.lorentz_only;
+        for (int k = 0; k < 2; ++k) {  // the field kernel's order: the action's species list
+            pro.sp[k] = c->states[SA.states[k]].new_data;
+            pro.r[k] = epi.a.r[k];
+        }
+        if (ok) {
+            const StatePhys* const sp2[2] = {&sa.sp, &sb.sp};
+            const double* const in2[2] = {nullptr, nullptr};
+            double* const out2[2] = {nullptr, nullptr};
+            unsigned long long* const red2[2] = {nullptr, nullptr};
+            ok = c->L->ctu_march2(c->g, sp2, in2, out2, ctu_flag[qs[0]], dt, c->touches, nullptr, red2, 0, &pro, c->stream) != 0 &&
+                 c->L->ctu_march_field(c->g, sf.sp, nullptr, nullptr, ctu_flag[epi_q], dt, c->touches, &epi, 0, &pro, c->stream) != 0;
+        }
+        if (!ok) pro.on = 0;
+    }
+    c->last_prologue = pro.on;
+    c->last_epilogue = epi_q >= 0;
+    bool src_split = false;
+    IBox src_inner;
+    if (src >= 0 && !pro.on) {
+        SourceArgs a = source_args(c, c->actions[src], true);
+        if (coll >= 0) a.coll = coll_args(c, c->actions[coll]);
+        IBox inner;
+        bool has_inner = !overlap && split_any && c->overlap != 0;
+        for (int d = 0; d < 3; ++d) {
+            const int w = d < c->g.dim ? c->g.ng[d] : 0;
+            inner.lo[d] = w;
+            inner.hi[d] = c->g.n[d] - 1 - w;
+            has_inner = has_inner && (d >= c->g.dim || inner.hi[d] >= inner.lo[d]);
+        }
+        if (has_inner) {
+            // frame: slabs peeled off dimension by dimension (disjoint), on the main stream
+            IBox rest;
+            for (int d = 0; d < 3; ++d) {
+                rest.lo[d] = 0;
+                rest.hi[d] = c->g.n[d] - 1;
+            }
+            {
+                ProfScope prof(c, CMFP_PROF_SOURCE);
+                for (int d = c->g.dim - 1; d >= 0; --d) {
+                    IBox lo_slab = rest, hi_slab = rest;
+                    lo_slab.hi[d] = inner.lo[d] - 1;
+                    hi_slab.lo[d] = inner.hi[d] + 1;
+                    if (!c->L->source_fused_box(c->g, a, 0.5 * dt, lo_slab, c->stream)) return 0;
+                    if (!c->L->source_fused_box(c->g, a, 0.5 * dt, hi_slab, c->stream)) return 0;
+                    rest.lo[d] = inner.lo[d];
+                    rest.hi[d] = inner.hi[d];
+                }
+            }
+            HIPCHK(c, hipEventRecord(c->ev_src, c->stream));  // everything of the previous step, and the frame
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_src, 0));
+            src_split = true;
+            src_inner = inner;
+        } else {
+            ProfScope prof(c, CMFP_PROF_SOURCE);
+            if (!c->L->source_fused(c->g, a, 0.5 * dt, 0, c->stream)) return 0;
+        }
     }
     // Halo/compute overlap: where the block is split between ranks, the flux update of the tiles
     // whose stencils stay inside valid cells runs on a second stream while the ghost layers are
@@ -853,7 +899,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     // the exchange, which is what hides the halo traffic of a 2-D block)
     const bool field_whole = overlap && epi_q >= 0 && !f3d[list[epi_q]] &&
                              c->L->ctu_march_field(c->g, c->states[list[epi_q]].sp, nullptr, nullptr, ctu_flag[epi_q], dt, c->touches, &epi,
-                                                   0 | tile_flag, c->stream) != 0;
+                                                   0 | tile_flag, nullptr, c->stream) != 0;
     const Ptr3 F1{{c->gF1[0], c->gF1[1], c->gF1[2]}}, F2{{c->gF2[0], c->gF2[1], c->gF2[2]}};
     auto slot_of = [&](const StateRT& s) { return s.sp.kind == CMFP_STATE_HYDRO ? CMFP_PROF_CTU_HYDRO : CMFP_PROF_CTU_FIELD; };
     // two species of the same physics share one wave-marching launch (MarchStates, mfp_march.hip)
@@ -865,7 +911,16 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         const double* const in[2] = {a.new_data, b.new_data};
         double* const out[2] = {a.alt, b.alt};
         unsigned long long* const red[2] = {slots[qa], slots[qb]};
-        return c->L->ctu_march2(c->g, sp, in, out, ctu_flag[qa], dt, c->touches, c->d_err, red, part, st) != 0;
+        SourcePro pr = pro;
+        if (pro.on) {  // the launch's order of the species
+            const cmfp_action_desc& SA = c->actions[src];
+            const int ids[2] = {list[qa], list[qb]};
+            for (int k = 0; k < 2; ++k) {
+                pr.sp[k] = c->states[ids[k]].new_data;
+                pr.r[k] = ids[k] == SA.states[0] ? epi.a.r[0] : epi.a.r[1];
+            }
+        }
+        return c->L->ctu_march2(c->g, sp, in, out, ctu_flag[qa], dt, c->touches, c->d_err, red, part, pro.on ? &pr : nullptr, st) != 0;
     };
     if (overlap) {
         HIPCHK(c, hipEventRecord(c->ev_src, c->stream));  // source stage A (and the slot resets) done
@@ -882,6 +937,8 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
                 c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, 1 | tile_flag, c->stream2);
             else if (k + 1 < order.size() && pair_launch(q, order[k + 1], 1, c->stream2))
                 ++k;
+            else if (pro.on)
+                return fail(c, CMFP_ERR_INVALID, "source prologue: the paired hydro launch was refused after its probe succeeded");
             else
                 c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], 1 | tile_flag, c->stream2);
         }
@@ -912,12 +969,17 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         // launches (second stream) update: wait for them
         if (overlap && (int)q == epi_q) HIPCHK(c, hipStreamWaitEvent(c->stream, field_whole ? c->ev_int : c->ev_hyd, 0));
         ProfScope prof(c, slot_of(s), c->stream, !overlap || ((int)q == epi_q && field_whole));
-        if ((int)q == epi_q && field_whole)
+        if ((int)q == epi_q && pro.on) {
+            if (!c->L->ctu_march_field(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, &epi, 0, &pro, c->stream))
+                return fail(c, CMFP_ERR_INVALID, "source prologue: the field launch was refused after its probe succeeded");
+        } else if ((int)q == epi_q && field_whole)
             c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, 0 | tile_flag, c->stream);
         else if ((int)q == epi_q && !f3d[list[q]])
             c->L->ctu_field_src(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, epi, (overlap ? 2 : 0) | tile_flag, c->stream);
         else if (k + 1 < order.size() && pair_launch(q, order[k + 1], overlap ? 2 : 0, c->stream))
             ++k;
+        else if (pro.on)
+            return fail(c, CMFP_ERR_INVALID, "source prologue: the paired hydro launch was refused after its probe succeeded");
         else if (tiled[list[q]])
             c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], (overlap ? 2 : 0) | tile_flag,
                             c->stream);
@@ -1035,6 +1097,7 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     c->device = device;
     c->stream = (hipStream_t)stream;
     if (const char* e = std::getenv("CMFP_SRC_EPILOGUE")) c->src_epilogue = std::atoi(e) != 0;
+    if (const char* e = std::getenv("CMFP_SRC_PROLOGUE")) c->src_prologue = std::atoi(e) != 0;
     c->L = params->fp_mode == CMFP_FP_FAST ? fast::launchers() : strict::launchers();
     c->nsteps = params->time_integrator == CMFP_TI_EULER ? 1 : 2;  // MFP_config.cpp:73-81
     HIPCHK(c, hipSetDevice(device));
@@ -1137,6 +1200,18 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
             if (c->states[A.states[i]].sp.kind != CMFP_STATE_HYDRO)
                 return fail(c, CMFP_ERR_INVALID, "source action: species must be hydro states");
     }
+    for (auto& st : c->states) st.fill_ng = st.sp.ng;
+    // Where the source prologue may run (decided per step in advance_strang_fused; the conditions that do not
+    // change are checked here) the field's kernel evaluates stage A from the species' values over its own stencil
+    // reach: their ghost layers are kept current to the field's width
+    if (c->src_prologue && params->fp_mode == CMFP_FP_FAST && geom->dim == 2 && params->time_integrator == CMFP_TI_STRANG &&
+        !c->touches[0][0] && !c->touches[0][1] && !c->touches[1][0] && !c->touches[1][1])
+        for (const auto& A : c->actions)
+            if ((A.kind == CMFP_ACTION_LORENTZ || (A.kind == CMFP_ACTION_PLASMA5 && A.solver != CMFP_SOLVER_IMPLICIT)) && A.n_states == 3)
+                for (int i = 0; i < 2; ++i) {
+                    StateRT& st = c->states[A.states[i]];
+                    st.fill_ng = std::max(st.fill_ng, c->states[A.states[2]].sp.ng);
+                }
     HIPCHK(c, hipMalloc((void**)&c->d_err, sizeof(int)));
     HIPCHK(c, hipMalloc((void**)&c->d_errcell, sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
@@ -1645,6 +1720,7 @@ int cmfp_advance(cmfp_context* c, double, double dt) {
 }
 
 int cmfp_last_advance_fused(const cmfp_context* c) { return c ? c->last_fused : 0; }
+int cmfp_last_source_fusion(const cmfp_context* c) { return c && c->last_fused ? (c->last_prologue | (c->last_epilogue << 1)) : 0; }
 
 int cmfp_profile_enable(cmfp_context* c, int on) {
     if (!c) return CMFP_ERR_INVALID;
@@ -1713,7 +1789,7 @@ int cmfp_fill_patch(cmfp_context* c, int s) {
 }
 long long cmfp_halo_count(const cmfp_context* c, int s, int dim) {
     if (!c || s < 0 || s >= (int)c->states.size() || dim < 0 || dim >= c->g.dim) return CMFP_ERR_INVALID;
-    long long n = (long long)c->states[s].sp.nc * c->states[s].sp.ng;
+    long long n = (long long)c->states[s].sp.nc * c->states[s].fill_ng;
     for (int t = 0; t < 3; ++t)
         if (t != dim) n *= c->g.ext[t];
     return n;
@@ -1724,7 +1800,7 @@ int cmfp_halo_pack(cmfp_context* c, int s, int dim, int side, double* dbuf) {
     if (s < 0 || s >= (int)c->states.size() || dim < 0 || dim >= c->g.dim || !dbuf)
         return fail(c, CMFP_ERR_INVALID, "bad halo arguments");
     StateRT& st = c->states[s];
-    c->L->pack(c->g, st.sp.nc, st.sp.ng, st.new_data, dim, side, dbuf, 0, c->stream);
+    c->L->pack(c->g, st.sp.nc, st.fill_ng, st.new_data, dim, side, dbuf, 0, c->stream);
     return CMFP_OK;
 }
 int cmfp_halo_unpack(cmfp_context* c, int s, int dim, int side, const double* dbuf) {
@@ -1733,7 +1809,7 @@ int cmfp_halo_unpack(cmfp_context* c, int s, int dim, int side, const double* db
     if (s < 0 || s >= (int)c->states.size() || dim < 0 || dim >= c->g.dim || !dbuf)
         return fail(c, CMFP_ERR_INVALID, "bad halo arguments");
     StateRT& st = c->states[s];
-    c->L->pack(c->g, st.sp.nc, st.sp.ng, st.new_data, dim, side, const_cast<double*>(dbuf), 1, c->stream);
+    c->L->pack(c->g, st.sp.nc, st.fill_ng, st.new_data, dim, side, const_cast<double*>(dbuf), 1, c->stream);
     return CMFP_OK;
 }
 

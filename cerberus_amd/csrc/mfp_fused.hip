@@ -502,7 +502,7 @@ int ctu_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout
 
 // defined in mfp_march_field.hip
 int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
-                    const int touches[3][2], const SourceEpi* epi, int part, hipStream_t st);
+                    const int touches[3][2], const SourceEpi* epi, int part, const SourcePro* pro, hipStream_t st);
 
 int ctu_march3d(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
                 const int touches[3][2], int* err, unsigned long long* red, hipStream_t st);
@@ -516,7 +516,7 @@ int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout
         return (tile_only || part != 0) ? 0 : ctu_march3d(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, st);
     if (g.dim != 2) return 0;
     if (!tile_only && ctu_march(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, part, st)) return 1;
-    if (!tile_only && ctu_march_field(g, sp, Uin, Uout, do_ctu, dt, touches, nullptr, part, st)) return 1;
+    if (!tile_only && ctu_march_field(g, sp, Uin, Uout, do_ctu, dt, touches, nullptr, part, nullptr, st)) return 1;
 #define HY(R, F)                                                                                                    \
     if (sp.recon == R && sp.flux == F)                                                                              \
         return launch2d<HydroF<R, F>, CMFP_HBX, CMFP_HBY>(g, sp.hp, sp, Uin, Uout, do_ctu, dt, touches, err, red, part, st);
@@ -550,7 +550,7 @@ int ctu_interior(const Geo& g, const StatePhys& sp, int do_ctu, int flags, IBox*
 int ctu_field_src(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
                   const int touches[3][2], const SourceEpi& epi, int part, hipStream_t st) {
     if (g.dim != 2 || sp.kind != 1 || epi.a.implicit || epi.a.coll.on) return 0;
-    if (!(part & 0x100) && ctu_march_field(g, sp, Uin, Uout, do_ctu, dt, touches, &epi, part, st)) return 1;
+    if (!(part & 0x100) && ctu_march_field(g, sp, Uin, Uout, do_ctu, dt, touches, &epi, part, nullptr, st)) return 1;
     part &= 0xff;
 #define FS(R, NS) \
     if (sp.recon == R && epi.ns == NS) \

@@ -1403,12 +1403,12 @@ int ctu_field3d(const Geo&, const StatePhys&, const double* Uin, double* Uout, c
                 const int touches[3][2], const SourceEpi* epi, hipStream_t);
 // defined in mfp_march_field.hip
 int ctu_march_field(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt, const int touches[3][2],
-                    const SourceEpi* epi, int part, hipStream_t);
+                    const SourceEpi* epi, int part, const SourcePro* pro, hipStream_t);
 void field_vacuum_check(const Geo&, const double* U, int* flag, hipStream_t);
 int ctu_interior(const Geo&, const StatePhys&, int do_ctu, int flags, IBox* box);
 // defined in mfp_march.hip
 int ctu_march2(const Geo&, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
-               const int touches[3][2], int* err, unsigned long long* const red[2], int part, hipStream_t);
+               const int touches[3][2], int* err, unsigned long long* const red[2], int part, const SourcePro* pro, hipStream_t);
 static int l_ctu_gather(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
                         int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
     if (g.dim == 1) return ctu_gather_1(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);

@@ -23,6 +23,7 @@
 #include <cstring>
 
 #include "mfp_march.h"
+#include "mfp_source.h"
 
 namespace CMFP_NS {
 static constexpr int MW = 60;  // columns a strip updates
@@ -39,8 +40,13 @@ struct MarchStates {
     unsigned long long* red[2];
 };
 
-template <class Phys, bool HAS_BC, bool REDUCE>
-__global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S, double dt, MarchBC bc, int* err, MarchSel sel) {
+// PRO: Strang source stage A (explicit plasma5 / Lorentz over the launch's two species) applied to every row as
+// it is loaded (SourcePro, mfp_source.h): the wave also reads the other species' momentum and D, B of the field
+// (14 values per cell instead of 5) and the stage-A values a row's update starts from are rebuilt from its
+// primitives instead of being read again.  FAST arithmetic only.
+template <class Phys, bool HAS_BC, bool REDUCE, bool PRO>
+__global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S, double dt, MarchBC bc, int* err, MarchSel sel,
+                                                      SourcePro pro) {
     constexpr int RECON = Phys::RECON;
     static_assert(ReconTraits<RECON>::SL == 3 && Phys::IS_HYDRO, "three-point hydro reconstructions");
     dt = launch_dt(g, dt);  // device-resident time step (cmfp_advance_steps)
@@ -74,26 +80,46 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
     const double dtdx = uni(dt / g.dx[0]), dtdy = uni(dt / g.dx[1]);
     const long col = g.at(ic, 0, 0);
     bool bad = false;
+    constexpr int NL = PRO ? 14 : 5;  // values of a cell in flight
+    const double* __restrict__ Uoth = PRO ? S.Uin[1 - which] : nullptr;
+    const double* __restrict__ Fin = PRO ? pro.fld : nullptr;
+    const ProArgs pa = pro_args(pro, which);
+    const double hdt = 0.5 * dt;
+    const SourceCoef kf = source_coef(pa, hdt);
 
     auto load_row = [&](int row, double* U) {
         const long c = col + (long)row * g.sj;
 #pragma unroll
         for (int n = 0; n < 5; ++n) U[n] = Uin[c + n * g.sc];
     };
-    // conserved -> {rho, u, v, w, eps = p / (gamma - 1)} (MFP_hydro.cpp:847-862)
-    auto to_prim = [&](const double* U, double* Q) {
+    // what stage A needs beside the species' own values: the other species' momentum, D and B
+    auto load_row_pro = [&](int row, double* U) {
+        if constexpr (PRO) {
+            const long c = col + (long)row * g.sj;
+#pragma unroll
+            for (int n = 0; n < 3; ++n) U[5 + n] = Uoth[c + (1 + n) * g.sc];
+#pragma unroll
+            for (int n = 0; n < 6; ++n) U[8 + n] = Fin[c + n * g.sc];
+        }
+    };
+    // [stage A,] conserved -> {rho, u, v, w, eps = p / (gamma - 1)} (MFP_hydro.cpp:847-862)
+    auto to_prim = [&](double* U, double* Q) {
+        if constexpr (PRO) source_prologue_species(pa, kf, hdt, U, U + 5, U + 8);
         if (!Phys::cons2prim(P, U, Q)) bad = true;
         Q[H_P] = f_div(Q[H_P], gm1);
     };
 
-    double Qa[5], Qb[5], Un[5];
+    double Qa[5], Qb[5], Un[NL];
     {
-        double U[5];
+        double U[NL];
         load_row(ja - 2, U);
+        load_row_pro(ja - 2, U);
         to_prim(U, Qa);
         load_row(ja - 1, U);
+        load_row_pro(ja - 1, U);
         to_prim(U, Qb);
         load_row(ja, Un);
+        load_row_pro(ja, Un);
     }
     // carried from the previous iteration (row r - 1)
     double xlo_p[5], xhi_p[5];  // traced x-face states, not yet corrected
@@ -111,12 +137,21 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
         const bool live = r <= jb + 1;
         double Qc[5];
         to_prim(Un, Qc);
-        {
-            const int rn = r + 2 < jb + 2 ? r + 2 : jb + 2;  // rows past the segment's stencil reach are not touched
-            load_row(rn, Un);
+        const int rn = r + 2 < jb + 2 ? r + 2 : jb + 2;  // rows past the segment's stencil reach are not touched
+        load_row(rn, Un);
+        double Uold[5];  // what the update of row r - 1 starts from (used once r - 1 >= ja)
+        if constexpr (PRO) {
+            // the stage-A values of row r - 1 from its primitives (eps = E - ke); contractions written out so that
+            // both copies of this row pipeline round alike
+#pragma clang fp contract(off)
+            const double q2 = fma(Qa[H_W], Qa[H_W], fma(Qa[H_V], Qa[H_V], Qa[H_U] * Qa[H_U]));
+            Uold[0] = Qa[H_RHO], Uold[1] = Qa[H_U] * Qa[H_RHO], Uold[2] = Qa[H_V] * Qa[H_RHO], Uold[3] = Qa[H_W] * Qa[H_RHO];
+            Uold[4] = fma(0.5 * Qa[H_RHO], q2, Qa[H_P]);
+        } else {
+            const long c = col + (long)(r - 1) * g.sj;
+#pragma unroll
+            for (int n = 0; n < 5; ++n) Uold[n] = Uin[c + n * g.sc];
         }
-        double Uold[5];
-        load_row(r - 1, Uold);  // used once r - 1 >= ja
 
         // ---- reconstruction + half-step trace of row r (HydroState::calc_reconstruction,
         //      calc_time_averaged_faces)
@@ -181,6 +216,7 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
             if (live && lane_ok && ((!ok_hi && i >= -1 && i < n0) || (!ok_lo && i >= 0 && i <= n0))) bad = true;
         }
 
+        load_row_pro(rn, Un);  // requested here: half an iteration ahead is enough, and fewer values are live than at its start
         // ---- domain-face BCs (update_face_prim, do_all) + Riemann sweep 2
         double fy2[5] = {0, 0, 0, 0, 0};
         if (r >= ja) {
@@ -267,13 +303,21 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
 
 template <class Phys>
 static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2],
-                        double dt, const int touches[3][2], int* err, unsigned long long* const red[2], int part, hipStream_t st) {
+                        double dt, const int touches[3][2], int* err, unsigned long long* const red[2], int part, const SourcePro* pro,
+                        hipStream_t st) {
     if (g.ng[0] < 2 || g.ng[1] < 2) return 0;
     const bool has_int = g.n[0] >= 5 && g.n[1] >= 5;  // cells whose stencil footprint (+-2) stays inside valid cells
-    if (!Uin[0]) return part == 1 ? has_int : 1;
     MarchSel sel;
-    if (!march_select(g, part, 2, MW, n, sel)) return 1;
+    if (Uin[0] && !march_select(g, part, 2, MW, n, sel)) return 1;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
+    if (pro) {  // the prologue: FAST build, both species in the launch, no physical faces, stage C follows (no reduction here)
+#ifdef CMFP_FASTMATH
+        if (n != 2 || has_bc || red[0]) return 0;
+#else
+        return 0;
+#endif
+    }
+    if (!Uin[0]) return part == 1 ? has_int : 1;
     const MarchBC bc = make_march_bc(*sp[0], touches);
     MarchStates<Phys> S;
     std::memset(&S, 0, sizeof(S));
@@ -285,7 +329,16 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
         S.red[k] = red[k];
     }
     const dim3 grid(((sel.nwaves * n + 7) / 8) * 8), block(64);
-#define CMFP_LAUNCH(BC, RED) hipLaunchKernelGGL((k_ctu_march<Phys, BC, RED>), grid, block, 0, st, g, S, dt, bc, err, sel)
+    SourcePro pr;
+    std::memset(&pr, 0, sizeof(pr));
+#define CMFP_LAUNCH(BC, RED) hipLaunchKernelGGL((k_ctu_march<Phys, BC, RED, false>), grid, block, 0, st, g, S, dt, bc, err, sel, pr)
+#ifdef CMFP_FASTMATH
+    if (pro) {
+        pr = *pro;
+        hipLaunchKernelGGL((k_ctu_march<Phys, false, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr);
+        return 1;
+    }
+#endif
     if (red[0]) {
         if (has_bc) CMFP_LAUNCH(true, true); else CMFP_LAUNCH(false, true);
     } else {
@@ -306,7 +359,7 @@ int ctu_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout
     double* const out[2] = {Uout, nullptr};
     unsigned long long* const reds[2] = {red, nullptr};
 #define HY(R, F) \
-    if (sp.recon == R && sp.flux == F) return launch_march<HydroF<R, F>>(g, 1, sps, in, out, dt, touches, err, reds, part, st);
+    if (sp.recon == R && sp.flux == F) return launch_march<HydroF<R, F>>(g, 1, sps, in, out, dt, touches, err, reds, part, nullptr, st);
     HY(1, 0) HY(1, 1) HY(1, 2) HY(2, 0) HY(2, 1) HY(2, 2) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)
 #undef HY
     return 0;
@@ -324,16 +377,17 @@ bool ctu_march_interior(const Geo& g, const StatePhys& sp, int do_ctu, IBox& box
 int ctu_march3d2(const Geo& g, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
                  const int touches[3][2], int* err, unsigned long long* const red[2], hipStream_t st);
 int ctu_march2(const Geo& g, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
-               const int touches[3][2], int* err, unsigned long long* const red[2], int part, hipStream_t st) {
-    if (g.dim == 3) return part == 0 ? ctu_march3d2(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, st) : 0;
+               const int touches[3][2], int* err, unsigned long long* const red[2], int part, const SourcePro* pro, hipStream_t st) {
+    if (g.dim == 3) return part == 0 && !pro ? ctu_march3d2(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, st) : 0;
     const StatePhys &a = *sp[0], &b = *sp[1];
     if (g.dim != 2 || a.kind != 0 || b.kind != 0 || !do_ctu) return 0;
     if (a.recon != b.recon || a.flux != b.flux || a.nc != b.nc || (red[0] == nullptr) != (red[1] == nullptr)) return 0;
     if (std::memcmp(a.bc, b.bc, sizeof(a.bc)) != 0) return 0;
     static const bool off = std::getenv("CMFP_MARCH_PAIR") && std::atoi(std::getenv("CMFP_MARCH_PAIR")) == 0;
     if (off) return 0;
+    if (pro && a.flux == 2) return 0;  // the hybrid HLLE/HLLC kernel with the prologue does not fit two waves per SIMD
 #define HY(R, F) \
-    if (a.recon == R && a.flux == F) return launch_march<HydroF<R, F>>(g, 2, sp, Uin, Uout, dt, touches, err, red, part, st);
+    if (a.recon == R && a.flux == F) return launch_march<HydroF<R, F>>(g, 2, sp, Uin, Uout, dt, touches, err, red, part, pro, st);
     HY(1, 0) HY(1, 1) HY(1, 2) HY(2, 0) HY(2, 1) HY(2, 2) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)
 #undef HY
     return 0;

@@ -29,6 +29,8 @@
 // trace for O6), in FAST exactly 1 (the vacuum shortcut of the Riemann solver) — so mu and ep are neither read nor
 // rewritten: 8 components of traffic instead of 10.  Same device functions and operation order per value as the
 // staged and tiled kernels: STRICT results are bit-identical to them and to the oracle.
+#include <cstring>
+
 #include "mfp_march.h"
 #include "mfp_source.h"
 
@@ -43,9 +45,11 @@ CMFP_DEV double o6_interface(double s1, double s2, double s3, double s4, double 
     return (37.0 / 60.0) * (s3 + s4) - (2.0 / 15.0) * (s2 + s5) + (1.0 / 60.0) * (s1 + s6);
 }
 
-template <bool HAS_BC, int SRC>
+// PRO: Strang source stage A applied to every row as it enters the window (SourcePro, mfp_source.h): the wave
+// also reads {rho, mx, my, mz} of both species at the rows it loads (16 values per cell instead of 8).
+template <bool HAS_BC, int SRC, bool PRO>
 __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const double* __restrict__ Uin, double* __restrict__ Uout,
-                                                      double dt, MarchBC bc, MarchSel sel, typename EpiArg<SRC>::type epi) {
+                                                      double dt, MarchBC bc, MarchSel sel, typename EpiArg<SRC>::type epi, SourcePro pro) {
     typedef FieldF<5> Phys;
     __shared__ double ring_[FLD_NR * 8 * 64 + 2 * FLD_PAD];
     double* const ring = ring_ + FLD_PAD;
@@ -84,19 +88,36 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
 #endif
         }
 
+        constexpr int NL = PRO ? 16 : 8;  // values of a cell in flight
+        const double* __restrict__ Sa = PRO ? pro.sp[0] : nullptr;
+        const double* __restrict__ Sb = PRO ? pro.sp[1] : nullptr;
+        const ProArgs pa = pro_args(pro, 0);
+        const double hdt = 0.5 * dt;
+        const SourceCoef kf = source_coef(pa, hdt);
         auto load_row = [&](int row, double* U) {
             const long c = col + (long)row * g.sj;
 #pragma unroll
             for (int n = 0; n < 8; ++n) U[n] = Uin[c + n * g.sc];
+            if constexpr (PRO) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) U[8 + n] = Sa[c + n * g.sc];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) U[12 + n] = Sb[c + n * g.sc];
+            }
+        };
+        // a loaded row as the window holds it: after source stage A where that is this kernel's prologue
+        auto enter = [&](double* U) {
+            if constexpr (PRO) source_prologue_field(pa, kf, hdt, U, U + 8, U + 12);
         };
         auto slot_of = [&](int row) { return (row - row0) % FLD_NR; };
         auto at = [&](int slot, int n, int l) -> double& { return ring[(slot * 8 + n) * 64 + l]; };
 
         // prologue: rows ja - 4 .. ja + 1 into the window; I_y(ja - 3/2) from them; rows ja + 2, ja + 3 in flight
         // (two rows ahead: at one or two waves per SIMD nothing else hides the latency of the loads)
-        double Un[8], Un2[8];
+        double Un[NL], Un2[NL];
         for (int s = 0; s < FLD_NR; ++s) {
             load_row(row0 + s, Un);
+            enter(Un);
 #pragma unroll
             for (int n = 0; n < 8; ++n) at(s, n, lane) = Un[n];
         }
@@ -130,11 +151,11 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
             __syncthreads();  // every lane has finished reading the slot that is overwritten
             {
                 const int sn = slot_of(r + 3);
+                enter(Un);
 #pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    at(sn, n, lane) = Un[n];
-                    Un[n] = Un2[n];
-                }
+                for (int n = 0; n < 8; ++n) at(sn, n, lane) = Un[n];
+#pragma unroll
+                for (int n = 0; n < NL; ++n) Un[n] = Un2[n];
                 const int rn = r + 5 < jb + 4 ? r + 5 : jb + 4;  // rows past the segment's stencil reach are not touched
                 load_row(rn, Un2);
                 if constexpr (SRC > 0) {
@@ -337,11 +358,19 @@ static int fld_wave_slots() {
 // The field update of a vacuum block by the marching kernel; epi (may be null): the explicit Strang source
 // stage C as its epilogue.  Returns 0 where it does not apply (the caller then uses the tiled kernel).
 int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
-                    const int touches[3][2], const SourceEpi* epi, int part, hipStream_t st) {
+                    const int touches[3][2], const SourceEpi* epi, int part, const SourcePro* pro, hipStream_t st) {
     static const int off = std::getenv("CMFP_FIELD_MARCH") ? std::atoi(std::getenv("CMFP_FIELD_MARCH")) == 0 : 0;
     if (off || g.dim != 2 || sp.kind != 1 || !do_ctu || sp.recon != 5 || sp.flux != 10 || !sp.vacuum || part != 0) return 0;
     if (g.ng[0] < 4 || g.ng[1] < 4 || g.n[0] < 1 || g.n[1] < 1) return 0;
     if (epi && (epi->a.implicit || epi->a.coll.on || epi->ns < 1 || epi->ns > 2)) return 0;
+    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
+    if (pro) {  // source stage A as the prologue: FAST build, two species with the epilogue, no physical faces
+#ifdef CMFP_FASTMATH
+        if (!epi || epi->ns != 2 || has_bc) return 0;
+#else
+        return 0;
+#endif
+    }
     if (!Uin) return 1;  // coverage probe
     MarchSel sel;
     sel.nrect = 1;
@@ -365,10 +394,18 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
     sel.seg = seg;
     R.nseg = (g.n[1] + seg - 1) / seg;
     sel.nwaves = R.ns * R.nseg;
-    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
     const MarchBC bc = make_march_bc(sp, touches);
     const dim3 grid(((sel.nwaves + 7) / 8) * 8), block(64);
-#define FLD(BC, NS, E) hipLaunchKernelGGL((k_fld_march<BC, NS>), grid, block, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, E)
+    SourcePro pr;
+    std::memset(&pr, 0, sizeof(pr));
+#define FLD(BC, NS, E) hipLaunchKernelGGL((k_fld_march<BC, NS, false>), grid, block, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, E, pr)
+#ifdef CMFP_FASTMATH
+    if (pro) {
+        pr = *pro;
+        hipLaunchKernelGGL((k_fld_march<false, 2, true>), grid, block, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, *epi, pr);
+        return 1;
+    }
+#endif
     if (epi && epi->ns == 2) {
         if (has_bc) FLD(true, 2, *epi); else FLD(false, 2, *epi);
     } else if (epi && epi->ns == 1) {

@@ -25,9 +25,14 @@ __host__ __device__ static inline SourceCoef source_coef(const SourceArgs& a, do
 // One cell of Plasma5::explicit_solve (MFP_plasma5.cpp:161-236) /
 // Lorentz::calc_time_derivative (MFP_lorentz.cpp:129-189).  fU: field comps,
 // sU[n]: species comps {rho,mx,my,mz,E}.  Outputs are the increments.
-template <int MAXS>
-CMFP_DEV void plasma5_explicit_cell(const SourceArgs& a, const SourceCoef& kf, double dt, const double* fU,
+// (a: SourceArgs, or any type with n_species, r[], Larmor, lightspeed — ProArgs below)
+template <int MAXS, class Args>
+CMFP_DEV void plasma5_explicit_cell(const Args& a, const SourceCoef& kf, double dt, const double* fU,
                                     const double (*sU)[5], double (*sdU)[4], double* fdU /*Dx,Dy,Dz,phi,psi*/) {
+    // FAST: no contraction left to the compiler here — the fused multiply-adds are written out, so that every
+    // inlined copy of this function (the marching kernels hold several) rounds alike and a cell's result does not
+    // depend on which launch, segment or row parity it falls in.  (STRICT builds never contract.)
+#pragma clang fp contract(off)
     const double Larmor = a.Larmor, lightspeed = a.lightspeed;
     const double ep = fU[F_EP];
     const double Bx = fU[F_BX], By = fU[F_BY], Bz = fU[F_BZ];
@@ -38,6 +43,19 @@ CMFP_DEV void plasma5_explicit_cell(const SourceArgs& a, const SourceCoef& kf, d
         if (n < a.n_species) {
             const double rho = sU[n][0], mx = sU[n][1], my = sU[n][2], mz = sU[n][3];
             const double r = a.r[n];
+#ifdef CMFP_FASTMATH
+            charge_density = fma(rho, r, charge_density);
+            current_x = fma(r, mx, current_x);
+            current_y = fma(r, my, current_y);
+            current_z = fma(r, mz, current_z);
+            const double rhoinv = f_rcp(rho);
+            const double u = mx * rhoinv, v = my * rhoinv, w = mz * rhoinv;
+            const double k = dt * (rho * r / Larmor);
+            sdU[n][0] = k * fma(v, Bz, fma(-w, By, lightspeed * Ex));
+            sdU[n][1] = k * fma(w, Bx, fma(-u, Bz, lightspeed * Ey));
+            sdU[n][2] = k * fma(u, By, fma(-v, Bx, lightspeed * Ez));
+            sdU[n][3] = dt * (rho * r * lightspeed) / Larmor * fma(w, Ez, fma(v, Ey, u * Ex));
+#else
             charge_density += rho * r;
             current_x += r * mx;
             current_y += r * my;
@@ -47,13 +65,22 @@ CMFP_DEV void plasma5_explicit_cell(const SourceArgs& a, const SourceCoef& kf, d
             sdU[n][1] = dt * (rho * r / Larmor) * (lightspeed * Ey + w * Bx - u * Bz);
             sdU[n][2] = dt * (rho * r / Larmor) * (lightspeed * Ez + u * By - v * Bx);
             sdU[n][3] = dt * (rho * r * lightspeed) / Larmor * (u * Ex + v * Ey + w * Ez);
+#endif
         }
     }
+#ifdef CMFP_FASTMATH
+    fdU[0] = -kf.f1 * current_x;
+    fdU[1] = -kf.f1 * current_y;
+    fdU[2] = -kf.f1 * current_z;
+    fdU[3] = fma(kf.f2, charge_density, -fU[F_PHI] * kf.f3);
+    fdU[4] = -fU[F_PSI] * kf.f3;
+#else
     fdU[0] = -kf.f1 * current_x;
     fdU[1] = -kf.f1 * current_y;
     fdU[2] = -kf.f1 * current_z;
     fdU[3] = -fU[F_PHI] * kf.f3 + kf.f2 * charge_density;
     fdU[4] = -fU[F_PSI] * kf.f3;
+#endif
 }
 
 // per-cell contributions
@@ -81,9 +108,15 @@ CMFP_DEV double cell_plasma_dt(double Larmor, double Debye, double Bx, double By
 // explicit plasma5 / Lorentz, the arithmetic of k_source_rk2 in the same order:
 //   U1 = U0 + S(U0) ; U2 = U1 + S(U1) ; new = 0.5 U0 + 0.5 U2
 // f0: field comps, s0: species comps; fnew = {Dx,Dy,Dz,phi,psi}, snew[s] = {mx,my,mz,E} after the stage.
-template <int NS>
-CMFP_DEV void source_rk2_explicit_cell(const SourceArgs& a, const SourceCoef& kf, double dt, const double* f0,
+template <int NS, class Args>
+CMFP_DEV void source_rk2_explicit_cell(const Args& a, const SourceCoef& kf, double dt, const double* f0,
                                        const double (*s0)[5], double* fnew, double (*snew)[4]) {
+#pragma clang fp contract(off)  // as in plasma5_explicit_cell
+#ifdef CMFP_FASTMATH
+    auto half_sum = [](double x, double y) { return fma(0.5, x, 0.5 * y); };
+#else
+    auto half_sum = [](double x, double y) { return 0.5 * x + 0.5 * y; };
+#endif
     double f1[10], s1[NS][5], sdU[NS][4], fdU[5];
     plasma5_explicit_cell<NS>(a, kf, dt, f0, s0, sdU, fdU);
 #pragma unroll
@@ -107,13 +140,67 @@ CMFP_DEV void source_rk2_explicit_cell(const SourceArgs& a, const SourceCoef& kf
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const double U2 = s1[s][n + 1] + sdU[s][n];
-            snew[s][n] = 0.5 * s0[s][n + 1] + 0.5 * U2;
+            snew[s][n] = half_sum(s0[s][n + 1], U2);
         }
-    fnew[0] = 0.5 * f0[F_DX] + 0.5 * (f1[F_DX] + fdU[0]);
-    fnew[1] = 0.5 * f0[F_DY] + 0.5 * (f1[F_DY] + fdU[1]);
-    fnew[2] = 0.5 * f0[F_DZ] + 0.5 * (f1[F_DZ] + fdU[2]);
-    fnew[3] = 0.5 * f0[F_PHI] + 0.5 * (f1[F_PHI] + fdU[3]);
-    fnew[4] = 0.5 * f0[F_PSI] + 0.5 * (f1[F_PSI] + fdU[4]);
+    fnew[0] = half_sum(f0[F_DX], f1[F_DX] + fdU[0]);
+    fnew[1] = half_sum(f0[F_DY], f1[F_DY] + fdU[1]);
+    fnew[2] = half_sum(f0[F_DZ], f1[F_DZ] + fdU[2]);
+    fnew[3] = half_sum(f0[F_PHI], f1[F_PHI] + fdU[3]);
+    fnew[4] = half_sum(f0[F_PSI], f1[F_PSI] + fdU[4]);
+}
+
+// ---- Strang source stage A as the prologue of the CTU kernels (FAST arithmetic, 2-D, explicit plasma5 /
+// Lorentz over two species, block without physical faces).  Stage A (MFP_advance.cpp:146-197) is pointwise, so a
+// CTU kernel can apply it to every cell it loads — ghost cells included: a periodic or neighbour copy of the raw
+// values gives the same result as the copy of the result — instead of a launch of its own that reads and
+// rewrites all states.  Each kernel evaluates what its state needs of the coupled RK2 (a species: its own
+// momentum and energy; the field: D, phi, psi) and the compiler drops the rest.
+// (kernel argument: SourcePro, mfp_types.h)
+struct ProArgs {  // what plasma5_explicit_cell / source_rk2_explicit_cell / source_coef read
+    int n_species;
+    double r[2];
+    double Larmor, Debye, lightspeed, c_h, div_damp;
+    int lorentz_only;
+};
+__host__ __device__ static inline SourceCoef source_coef(const ProArgs& a, double dt) {
+    const double c_h = a.c_h;
+    const double c_d = a.div_damp != 0.0 ? c_h / a.div_damp : 0.0;
+    SourceCoef k;
+    k.f1 = dt * a.Larmor / (a.Debye * a.Debye * a.lightspeed);
+    k.f2 = dt * c_h * c_h * k.f1 / a.lightspeed;
+    k.f3 = c_d != 0.0 ? dt * c_h * c_h / (c_d * c_d) : 0.0;
+    return k;
+}
+// species `first` is entry 0 of the argument's lists (a hydro wave lists its own species first)
+CMFP_DEV ProArgs pro_args(const SourcePro& p, int first) {
+    ProArgs a;
+    a.n_species = 2;
+    a.r[0] = p.r[first];
+    a.r[1] = p.r[1 - first];
+    a.Larmor = p.Larmor, a.Debye = p.Debye, a.lightspeed = p.lightspeed, a.c_h = p.c_h, a.div_damp = p.div_damp;
+    a.lorentz_only = p.lorentz_only;
+    return a;
+}
+// A hydro wave: own = {rho, mx, my, mz, E} before stage A (in) / after it (out); oth = {mx, my, mz} of the other
+// species (its current enters E after the first RK2 stage); f = {Dx, Dy, Dz, Bx, By, Bz}, vacuum (ep = 1).
+CMFP_DEV void source_prologue_species(const ProArgs& a, const SourceCoef& kf, double hdt, double* own, const double* oth,
+                                      const double* f) {
+    const double f0[10] = {f[0], f[1], f[2], f[3], f[4], f[5], 0.0, 0.0, 1.0, 1.0};
+    const double s0[2][5] = {{own[0], own[1], own[2], own[3], own[4]}, {1.0, oth[0], oth[1], oth[2], 0.0}};
+    double fnew[5], snew[2][4];
+    source_rk2_explicit_cell<2>(a, kf, hdt, f0, s0, fnew, snew);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) own[n + 1] = snew[0][n];
+}
+// A field wave: f = {Dx, Dy, Dz, Bx, By, Bz, phi, psi} (in/out); sa, sb = {rho, mx, my, mz} of the two species
+CMFP_DEV void source_prologue_field(const ProArgs& a, const SourceCoef& kf, double hdt, double* f, const double* sa,
+                                    const double* sb) {
+    if (a.lorentz_only) return;
+    const double f0[10] = {f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], 1.0, 1.0};
+    const double s0[2][5] = {{sa[0], sa[1], sa[2], sa[3], 0.0}, {sb[0], sb[1], sb[2], sb[3], 0.0}};
+    double fnew[5], snew[2][4];
+    source_rk2_explicit_cell<2>(a, kf, hdt, f0, s0, fnew, snew);
+    f[F_DX] = fnew[0], f[F_DY] = fnew[1], f[F_DZ] = fnew[2], f[F_PHI] = fnew[3], f[F_PSI] = fnew[4];
 }
 
 // kernel argument of the source epilogue (SRC species; nothing without one)

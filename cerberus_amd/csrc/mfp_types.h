@@ -125,6 +125,17 @@ struct SourceEpi {
     unsigned long long* red_dt;        // 256 slots: min plasma / cyclotron dt (all-ones = empty)
 };
 
+// Strang source stage A evaluated by the 2-D marching CTU kernels on the cells they load (mfp_source.h):
+// explicit plasma5 / Lorentz over two species, FAST arithmetic, block without physical faces
+struct SourcePro {
+    int on;
+    const double* sp[2];  // the species' arrays the CTU kernels read (values before stage A)
+    const double* fld;    // the field's
+    double r[2];          // charge / mass of the species
+    double Larmor, Debye, lightspeed, c_h, div_damp;
+    int lorentz_only;
+};
+
 // ghost fill rule per component for one (dim, side)
 enum FillRule { FILL_SKIP = 0, FILL_WRAP = 1, FILL_FOEXTRAP = 2, FILL_EVEN = 3, FILL_ODD = 4 };
 struct FillRules {
@@ -208,11 +219,12 @@ struct Launchers {
     // the cells the interior launch (part 1) of ctu_fused / ctu_field_src updates (flags: bit 8 as in their `part`)
     int (*ctu_interior)(const Geo&, const StatePhys&, int do_ctu, int flags, IBox* box);
     // two 2-D hydro states of the same physics in one wave-marching launch (mfp_march.hip); 0: not covered, nothing launched
+    // pro (may be null): source stage A as the kernel's prologue; Uin[0] == nullptr probes (with pro: whether the prologue is covered)
     int (*ctu_march2)(const Geo&, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
-                      const int touches[3][2], int* err, unsigned long long* const red[2], int part, hipStream_t);
+                      const int touches[3][2], int* err, unsigned long long* const red[2], int part, const SourcePro* pro, hipStream_t);
     // 2-D vacuum field update by the wave-marching kernel (mfp_march_field.hip), epi may be null; 0: not covered
     int (*ctu_march_field)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt,
-                           const int touches[3][2], const SourceEpi* epi, int part, hipStream_t);
+                           const int touches[3][2], const SourceEpi* epi, int part, const SourcePro* pro, hipStream_t);
     // *flag (zero before the launch) becomes 1 if a valid cell of the field array has mu != 1 or ep != 1
     void (*field_vacuum_check)(const Geo&, const double* U, int* flag, hipStream_t);
     // the three factors of MFP_plasma5.cpp:123-129 as the source kernels compute them on the host

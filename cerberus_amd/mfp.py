@@ -228,6 +228,10 @@ class MFP:
         """0: staged kernels, 1: tiled fused kernels, 2: gather kernels (1-D / 3-D, or forced with fused=2)."""
         return int(self.L.cmfp_last_advance_fused(self.h))
 
+    def last_source_fusion(self):
+        """bit 0: source stage A ran inside the CTU kernels, bit 1: stage C inside the field's (cmfp_last_source_fusion)."""
+        return int(self.L.cmfp_last_source_fusion(self.h))
+
     def last_error_cell(self):
         """(state index, (i, j, k)) of the first offending cell of the last ERR_PHYSICS, or None where the
         failure left no invalid cell-centred value (cmfp_last_error_cell)."""

@@ -307,6 +307,15 @@ int cmfp_set_fused(cmfp_context* ctx, int enable);
  * kernels, 2 gather kernels (for at least one state). */
 int cmfp_last_advance_fused(const cmfp_context* ctx);
 
+/* Where the Strang source half steps (MFP_advance.cpp:146-197, 235-281) of the last fused
+ * cmfp_advance ran: bit 0 set = stage A inside the CTU kernels (applied to every cell they load:
+ * FAST arithmetic, 2-D, explicit plasma5 / Lorentz over two species, block without physical faces;
+ * CMFP_SRC_PROLOGUE=0 in the environment keeps it a launch of its own), bit 1 set = stage C inside
+ * the field's CTU kernel (CMFP_SRC_EPILOGUE=0 likewise).  0: launches of their own.  Diagnostic, like
+ * cmfp_last_advance_fused; the reference has one code path (pointwise loops in
+ * Plasma5::calc_time_derivative, MFP_plasma5.cpp:73-244). */
+int cmfp_last_source_fusion(const cmfp_context* ctx);
+
 /* Per-kernel device timing: HIP events recorded on the context's stream around
  * every launch of the fused kernels while enabled (the reference's nearest
  * analogue is its per-box wall-time cost, MFP_CTU_hydro.cpp:143,529-530).

@@ -1,0 +1,98 @@
+"""Source stage A as the prologue of the 2-D marching CTU kernels (FAST arithmetic; mfp_source.h).
+
+The prologue applies the Strang source half step (MFP_advance.cpp:146-197) to every cell a CTU kernel loads
+instead of rewriting the states in a launch of its own.  Checked here: it is the path a periodic two-fluid 2-D
+block takes (cmfp_last_source_fusion), its results stay within the north-star bound of the oracle, they agree
+with the separate launch to rounding, and blocks / option sets outside its cover keep the separate launch."""
+import os
+
+import numpy as np
+import pytest
+
+from cerberus_amd import abi, config, problems
+from helpers import rel_linf
+
+pytestmark = pytest.mark.gpu
+
+TOL_FAST = 1e-12      # north_star: relative L-inf on conserved variables after N steps
+TOL_SAME = 2e-14      # prologue against the separate stage-A launch (same arithmetic up to operation order)
+
+
+def _gpu(problem, prologue=True, **kw):
+    from cerberus_amd.mfp import MFP
+    old = os.environ.get("CMFP_SRC_PROLOGUE")
+    os.environ["CMFP_SRC_PROLOGUE"] = "1" if prologue else "0"   # read by cmfp_create
+    try:
+        m = MFP(problem, **kw)
+    finally:
+        if old is None:
+            del os.environ["CMFP_SRC_PROLOGUE"]
+        else:
+            os.environ["CMFP_SRC_PROLOGUE"] = old
+    m.init_data()
+    return m
+
+
+def _ot(nx, ny, **kw):
+    cfg = problems.orszag_tang_two_fluid_2d(nx, **kw)
+    cfg["n_cell"] = [nx, ny]
+    return cfg
+
+
+@pytest.mark.parametrize("shape,steps", [((48, 48), 8), ((130, 70), 6), ((256, 256), 20), ((61, 9), 4)])
+@pytest.mark.parametrize("source", ["plasma5", "Lorentz"])
+def test_prologue_matches_oracle_and_separate_launch(oracle, shape, steps, source):
+    cfg = _ot(*shape, source=source)
+    P = config.Problem(cfg, fp_mode=abi.FP_FAST)
+    ref = oracle.OracleSim(P, max_grid_size=32)
+    dts_ref = ref.run(steps)
+    a, b = _gpu(P, prologue=True), _gpu(P, prologue=False)
+    da, db = a.run(steps), b.run(steps)
+    assert a.last_advance_path() == 1 and b.last_advance_path() == 1
+    assert a.last_source_fusion() == 3, "stage A and stage C inside the CTU kernels"
+    assert b.last_source_fusion() == 2, "CMFP_SRC_PROLOGUE=0 keeps stage A a launch of its own"
+    np.testing.assert_allclose(da, dts_ref, rtol=1e-12)
+    np.testing.assert_allclose(da, db, rtol=1e-13)
+    for s in range(a.n_states):
+        ua, ub, ur = a.download(s), b.download(s), ref.get_state(s)
+        assert rel_linf(ua, ur) <= TOL_FAST, (P.state_names[s], rel_linf(ua, ur))
+        assert rel_linf(ua, ub) <= TOL_SAME, (P.state_names[s], rel_linf(ua, ub))
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("device_dt", [True, False])
+def test_prologue_split_launches_and_dt_modes(oracle, device_dt):
+    """interior / frame launches (overlap=2 on an unsplit block) and both time-step modes give what the single
+    launch gives, bit for bit: the prologue is pointwise on what each launch loads"""
+    P = config.Problem(_ot(130, 70), fp_mode=abi.FP_FAST)
+    a, b = _gpu(P, overlap=2, device_dt=device_dt), _gpu(P, overlap=0, device_dt=True)
+    da, db = a.run(5), b.run(5)
+    assert a.last_source_fusion() == 3 and b.last_source_fusion() == 3
+    assert da == db
+    for s in range(a.n_states):
+        assert np.array_equal(a.download(s), b.download(s)), P.state_names[s]
+    a.close()
+    b.close()
+
+
+def test_prologue_not_taken_outside_its_cover(oracle):
+    """physical faces (GEM walls), STRICT arithmetic, the implicit solve and 3-D blocks keep stage A a launch of
+    its own — and their results stay what they were"""
+    cases = [
+        (problems.gem_reconnection_2d(48, 24), abi.FP_FAST, 4),
+        (_ot(48, 48), abi.FP_STRICT, 4),
+        (_ot(48, 48, solver="implicit"), abi.FP_FAST, 3),
+        (problems.richtmyer_meshkov_3d(24, 12, 12), abi.FP_FAST, 3),
+    ]
+    for cfg, mode, steps in cases:
+        P = config.Problem(cfg, fp_mode=mode)
+        ref = oracle.OracleSim(P)
+        ref.run(steps)
+        m = _gpu(P)
+        m.run(steps)
+        assert m.last_advance_path() != 0
+        assert (m.last_source_fusion() & 1) == 0
+        for s in range(m.n_states):
+            assert rel_linf(m.download(s), ref.get_state(s)) <= TOL_FAST, P.state_names[s]
+        m.close()
