@@ -25,20 +25,28 @@ def _worker(rank, world, port, which, batched, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        P = config.Problem(_cfg(which), fp_mode=abi.FP_STRICT)
+        P = config.Problem(_cfg(which), fp_mode=_mode(which))
         m = MFP(P, device=0, rank=rank, world=world, exchange_device="cpu", batched_exchange=batched)
         m.init_data()
         dts = m.run(5)
         out = {"dts": dts, "lo": m.block_lo, "n": m.block_n, "fused": m.last_advance_fused(), "device_dt": m._device_dt,
-               "data": [m.download(s) for s in range(m.n_states)]}
+               "fusion": m.last_source_fusion(), "data": [m.download(s) for s in range(m.n_states)]}
         ret[rank] = out
         m.close()
     finally:
         dist.destroy_process_group()
 
 
+def _mode(which):
+    """'<case>@fast': the FAST arithmetic bench.py measures (two-fluid 2-D blocks without physical faces then run the
+    source stage A inside the CTU kernels, and the species' halos are as wide as the field's)"""
+    from cerberus_amd import abi
+    return abi.FP_FAST if which.endswith("@fast") else abi.FP_STRICT
+
+
 def _cfg(which):
     from cerberus_amd import problems
+    which = which.split("@")[0]
     if which == "ot":
         return problems.orszag_tang_two_fluid_2d(32)
     if which == "ot512":        # blocks of 512 x 256 / 256 x 256: several strips, segments and tile rows per rank
@@ -77,7 +85,10 @@ def _free_port():
 @pytest.mark.parametrize("world,which,batched", [(2, "ot", True), (4, "ot", True), (4, "ot", False), (4, "gem", True), (4, "ot96", True), (2, "ot96", False), (2, "ot512", True), (4, "ot512", True),
                                                  (4, "rmi3d", True), (4, "rmi3d24", True), (2, "rmi3d24", False), (4, "inflow", True), (2, "inflow", False),
                                                  # eight ranks = the 2 x 4 (2-D) and 2 x 2 x 2 (3-D) process grids of the N = 8 scaling run
-                                                 (8, "ot512", True), (8, "ot96", True), (8, "gem64", True), (8, "rmi3d24", True)] +
+                                                 (8, "ot512", True), (8, "ot96", True), (8, "gem64", True), (8, "rmi3d24", True),
+                                                 # FAST arithmetic: source stage A as the CTU kernels' prologue on split blocks
+                                                 (2, "ot96@fast", True), (4, "ot96@fast", False), (4, "ot512@fast", True), (8, "ot512@fast", True),
+                                                 (4, "gem@fast", True), (4, "rmi3d24@fast", True)] +
                                                 [(2 + 2 * (k % 2), f"rand{k}", k % 3 != 0) for k in range(10)])
 def test_decomposed_run_equals_single_rank(world, which, batched):
     import torch.multiprocessing as mp
@@ -97,18 +108,22 @@ def test_decomposed_run_equals_single_rank(world, which, batched):
     assert not hung, "ranks did not finish (mismatched exchange pattern?)"
     for p in procs:
         assert p.exitcode == 0
-    P = config.Problem(_cfg(which), fp_mode=abi.FP_STRICT)
+    P = config.Problem(_cfg(which), fp_mode=_mode(which))
     m = MFP(P, device=0)
     m.init_data()
     dts = m.run(5)
     full = [m.download(s) for s in range(m.n_states)]
+    fusion = m.last_source_fusion()
     m.close()
+    if which.startswith("ot") and which.endswith("@fast"):
+        assert fusion == 3
     for r in range(world):
         o = ret[r]
         assert o["dts"] == dts
+        assert o["fusion"] == fusion
         if not which.startswith("rand"):
-            assert o["fused"] == (which != "inflow")
-            assert o["device_dt"] == (which != "inflow")     # cmfp_advance_steps with the cross-rank dt minimum on the device
+            assert o["fused"] == (which.split("@")[0] != "inflow")
+            assert o["device_dt"] == (which.split("@")[0] != "inflow")     # cmfp_advance_steps with the cross-rank dt minimum on the device
         lo, n = o["lo"], o["n"]
         for s in range(len(full)):
             ref = full[s][:, lo[2]:lo[2] + n[2], lo[1]:lo[1] + n[1], lo[0]:lo[0] + n[0]]
