@@ -756,7 +756,8 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     }
     // Strang stage A as the prologue of the marching kernels (mfp_source.h): FAST arithmetic, 2-D, the two species
     // of an explicit plasma5 / Lorentz action in one paired hydro launch, the field on the marching vacuum kernel
-    // with stage C as its epilogue, no physical face on this block.  Then no kernel of the step rewrites a state in
+    // with stage C as its epilogue; physical faces where their ghost cells are signed copies of one valid cell.
+    // Then no kernel of the step rewrites a state in
     // place: the ghost fills and the exchange move the values of the previous step, the CTU kernels apply stage A
     // to what they load.
     SourcePro pro;
@@ -782,6 +783,25 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
             pro.sp[k] = c->states[SA.states[k]].new_data;
             pro.r[k] = epi.a.r[k];
         }
+        // physical faces: every component of the three states must be a signed copy of one and the same valid cell
+        // there — all mirror images (reflect_even / reflect_odd) or all the first valid cell (foextrap)
+        for (int d = 0; d < 2 && ok; ++d)
+            for (int side = 0; side < 2 && ok; ++side) {
+                pro.touch[d][side] = c->touches[d][side];
+                if (!c->touches[d][side]) continue;
+                const FillRules ra = bc_rules(sa, d, side), rb = bc_rules(sb, d, side), rf = bc_rules(sf, d, side);
+                int n_mirror = 0, n_copy = 0;
+                for (int n = 0; n < 5; ++n) {
+                    ok = ok && ra.rule[n] == rb.rule[n];
+                    (ra.rule[n] == FILL_FOEXTRAP ? n_copy : n_mirror)++;
+                    if (ra.rule[n] == FILL_ODD) pro.odd_h[d][side] |= 1u << n;
+                }
+                for (int n = 0; n < 8; ++n) {
+                    (rf.rule[n] == FILL_FOEXTRAP ? n_copy : n_mirror)++;
+                    if (rf.rule[n] == FILL_ODD) pro.odd_f[d][side] |= 1u << n;
+                }
+                ok = ok && (n_mirror == 0 || n_copy == 0);
+            }
         if (ok) {
             const StatePhys* const sp2[2] = {&sa.sp, &sb.sp};
             const double* const in2[2] = {nullptr, nullptr};
@@ -1204,8 +1224,7 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     // Where the source prologue may run (decided per step in advance_strang_fused; the conditions that do not
     // change are checked here) the field's kernel evaluates stage A from the species' values over its own stencil
     // reach: their ghost layers are kept current to the field's width
-    if (c->src_prologue && params->fp_mode == CMFP_FP_FAST && geom->dim == 2 && params->time_integrator == CMFP_TI_STRANG &&
-        !c->touches[0][0] && !c->touches[0][1] && !c->touches[1][0] && !c->touches[1][1])
+    if (c->src_prologue && params->fp_mode == CMFP_FP_FAST && geom->dim == 2 && params->time_integrator == CMFP_TI_STRANG)
         for (const auto& A : c->actions)
             if ((A.kind == CMFP_ACTION_LORENTZ || (A.kind == CMFP_ACTION_PLASMA5 && A.solver != CMFP_SOLVER_IMPLICIT)) && A.n_states == 3)
                 for (int i = 0; i < 2; ++i) {

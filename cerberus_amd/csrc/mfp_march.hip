@@ -103,8 +103,30 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
         }
     };
     // [stage A,] conserved -> {rho, u, v, w, eps = p / (gamma - 1)} (MFP_hydro.cpp:847-862)
-    auto to_prim = [&](double* U, double* Q) {
-        if constexpr (PRO) source_prologue_species(pa, kf, hdt, U, U + 5, U + 8);
+    auto to_prim = [&](double* U, double* Q, int row) {
+        if constexpr (PRO) {
+            ProMask m{0u, 0u};
+            bool any = false;
+            if constexpr (HAS_BC) {  // ghost cells of a physical face: stage A of the valid cell they mirror, signs set again
+                m = pro_mask(pro, i, row, n0, n1);
+                any = __builtin_amdgcn_ballot_w64((m.h | m.f) != 0u) != 0;
+                if (any) {
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) U[n] = pro_flip(U[n], m.h, n);
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) U[5 + n] = pro_flip(U[5 + n], m.h, 1 + n);
+#pragma unroll
+                    for (int n = 0; n < 6; ++n) U[8 + n] = pro_flip(U[8 + n], m.f, n);
+                }
+            }
+            source_prologue_species(pa, kf, hdt, U, U + 5, U + 8);
+            if constexpr (HAS_BC) {
+                if (any) {
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) U[n] = pro_flip(U[n], m.h, n);
+                }
+            }
+        }
         if (!Phys::cons2prim(P, U, Q)) bad = true;
         Q[H_P] = f_div(Q[H_P], gm1);
     };
@@ -114,10 +136,10 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
         double U[NL];
         load_row(ja - 2, U);
         load_row_pro(ja - 2, U);
-        to_prim(U, Qa);
+        to_prim(U, Qa, ja - 2);
         load_row(ja - 1, U);
         load_row_pro(ja - 1, U);
-        to_prim(U, Qb);
+        to_prim(U, Qb, ja - 1);
         load_row(ja, Un);
         load_row_pro(ja, Un);
     }
@@ -136,7 +158,7 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
     auto march_row = [&](const int r) __attribute__((always_inline)) {
         const bool live = r <= jb + 1;
         double Qc[5];
-        to_prim(Un, Qc);
+        to_prim(Un, Qc, r + 1 < jb + 2 ? r + 1 : jb + 2);
         const int rn = r + 2 < jb + 2 ? r + 2 : jb + 2;  // rows past the segment's stencil reach are not touched
         load_row(rn, Un);
         double Uold[5];  // what the update of row r - 1 starts from (used once r - 1 >= ja)
@@ -310,9 +332,9 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
     MarchSel sel;
     if (Uin[0] && !march_select(g, part, 2, MW, n, sel)) return 1;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
-    if (pro) {  // the prologue: FAST build, both species in the launch, no physical faces, stage C follows (no reduction here)
+    if (pro) {  // the prologue: FAST build, both species in the launch, stage C follows (no reduction here)
 #ifdef CMFP_FASTMATH
-        if (n != 2 || has_bc || red[0]) return 0;
+        if (n != 2 || red[0]) return 0;
 #else
         return 0;
 #endif
@@ -335,7 +357,10 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
 #ifdef CMFP_FASTMATH
     if (pro) {
         pr = *pro;
-        hipLaunchKernelGGL((k_ctu_march<Phys, false, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr);
+        if (has_bc)
+            hipLaunchKernelGGL((k_ctu_march<Phys, true, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr);
+        else
+            hipLaunchKernelGGL((k_ctu_march<Phys, false, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr);
         return 1;
     }
 #endif

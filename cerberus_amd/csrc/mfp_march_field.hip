@@ -106,8 +106,28 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
             }
         };
         // a loaded row as the window holds it: after source stage A where that is this kernel's prologue
-        auto enter = [&](double* U) {
-            if constexpr (PRO) source_prologue_field(pa, kf, hdt, U, U + 8, U + 12);
+        auto enter = [&](double* U, int row) {
+            if constexpr (PRO) {
+                ProMask m{0u, 0u};
+                bool any = false;
+                if constexpr (HAS_BC) {  // ghost cells of a physical face: stage A of the valid cell they mirror, signs set again
+                    m = pro_mask(pro, i, row, n0, n1);
+                    any = __builtin_amdgcn_ballot_w64((m.h | m.f) != 0u) != 0;
+                    if (any) {
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) U[n] = pro_flip(U[n], m.f, n);
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) U[8 + n] = pro_flip(U[8 + n], m.h, n), U[12 + n] = pro_flip(U[12 + n], m.h, n);
+                    }
+                }
+                source_prologue_field(pa, kf, hdt, U, U + 8, U + 12);
+                if constexpr (HAS_BC) {
+                    if (any) {
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) U[n] = pro_flip(U[n], m.f, n);
+                    }
+                }
+            }
         };
         auto slot_of = [&](int row) { return (row - row0) % FLD_NR; };
         auto at = [&](int slot, int n, int l) -> double& { return ring[(slot * 8 + n) * 64 + l]; };
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
         double Un[NL], Un2[NL];
         for (int s = 0; s < FLD_NR; ++s) {
             load_row(row0 + s, Un);
-            enter(Un);
+            enter(Un, row0 + s);
 #pragma unroll
             for (int n = 0; n < 8; ++n) at(s, n, lane) = Un[n];
         }
@@ -151,7 +171,7 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
             __syncthreads();  // every lane has finished reading the slot that is overwritten
             {
                 const int sn = slot_of(r + 3);
-                enter(Un);
+                enter(Un, r + 3 < jb + 4 ? r + 3 : jb + 4);
 #pragma unroll
                 for (int n = 0; n < 8; ++n) at(sn, n, lane) = Un[n];
 #pragma unroll
@@ -364,9 +384,9 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
     if (g.ng[0] < 4 || g.ng[1] < 4 || g.n[0] < 1 || g.n[1] < 1) return 0;
     if (epi && (epi->a.implicit || epi->a.coll.on || epi->ns < 1 || epi->ns > 2)) return 0;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
-    if (pro) {  // source stage A as the prologue: FAST build, two species with the epilogue, no physical faces
+    if (pro) {  // source stage A as the prologue: FAST build, two species with the epilogue
 #ifdef CMFP_FASTMATH
-        if (!epi || epi->ns != 2 || has_bc) return 0;
+        if (!epi || epi->ns != 2) return 0;
 #else
         return 0;
 #endif
@@ -402,7 +422,10 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
 #ifdef CMFP_FASTMATH
     if (pro) {
         pr = *pro;
-        hipLaunchKernelGGL((k_fld_march<false, 2, true>), grid, block, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, *epi, pr);
+        if (has_bc)
+            hipLaunchKernelGGL((k_fld_march<true, 2, true>), grid, block, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, *epi, pr);
+        else
+            hipLaunchKernelGGL((k_fld_march<false, 2, true>), grid, block, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, *epi, pr);
         return 1;
     }
 #endif

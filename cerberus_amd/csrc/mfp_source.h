@@ -181,6 +181,25 @@ CMFP_DEV ProArgs pro_args(const SourcePro& p, int first) {
     a.lorentz_only = p.lorentz_only;
     return a;
 }
+// Sign masks of the cell (i, row) at the physical faces of the block (SourcePro::odd_*): which components of
+// the hydro (.x) and field (.y) states a ghost fill has negated there; 0 for a valid cell
+struct ProMask {
+    unsigned h, f;
+};
+CMFP_DEV ProMask pro_mask(const SourcePro& p, int i, int row, int n0, int n1) {
+    ProMask m{0u, 0u};
+    if (p.touch[0][0] && i < 0) m.h ^= p.odd_h[0][0], m.f ^= p.odd_f[0][0];
+    if (p.touch[0][1] && i >= n0) m.h ^= p.odd_h[0][1], m.f ^= p.odd_f[0][1];
+    if (p.touch[1][0] && row < 0) m.h ^= p.odd_h[1][0], m.f ^= p.odd_f[1][0];
+    if (p.touch[1][1] && row >= n1) m.h ^= p.odd_h[1][1], m.f ^= p.odd_f[1][1];
+    return m;
+}
+// v with its sign flipped where bit `bit` of mask is set
+CMFP_DEV double pro_flip(double v, unsigned mask, int bit) {
+    const int hi = __double2hiint(v) ^ (int)(((mask >> bit) & 1u) << 31);
+    return __hiloint2double(hi, __double2loint(v));
+}
+
 // A hydro wave: own = {rho, mx, my, mz, E} before stage A (in) / after it (out); oth = {mx, my, mz} of the other
 // species (its current enters E after the first RK2 stage); f = {Dx, Dy, Dz, Bx, By, Bz}, vacuum (ep = 1).
 CMFP_DEV void source_prologue_species(const ProArgs& a, const SourceCoef& kf, double hdt, double* own, const double* oth,

@@ -134,6 +134,13 @@ struct SourcePro {
     double r[2];          // charge / mass of the species
     double Larmor, Debye, lightspeed, c_h, div_damp;
     int lorentz_only;
+    // Physical faces of the block.  A ghost cell there holds +-1 times the values of one valid cell (its mirror
+    // image: reflect_even / reflect_odd; or the first valid cell: foextrap) for every component of every state, so
+    // stage A of the ghost cell is the same signs applied to stage A of those values: the kernels undo the signs,
+    // apply stage A and set the signs again (exact).  odd_*: bit n set = component n is reflect_odd on that face.
+    int touch[2][2];          // [d][side]
+    unsigned odd_h[2][2];     // hydro components (both species have the same rules)
+    unsigned odd_f[2][2];     // field components
 };
 
 // ghost fill rule per component for one (dim, side)

@@ -33,16 +33,28 @@ def _gpu(problem, prologue=True, **kw):
     return m
 
 
-def _ot(nx, ny, **kw):
+def _ot(nx, ny, faces="pp", **kw):
+    """two-fluid Orszag-Tang on nx x ny cells; faces: per direction p(eriodic), o(utflow: foextrap ghost cells) or
+    w(all: slipwall species, conducting-wall field = reflect_even / reflect_odd ghost cells)"""
     cfg = problems.orszag_tang_two_fluid_2d(nx, **kw)
     cfg["n_cell"] = [nx, ny]
+    wall = {k: {"fill_hydro_bc": "slipwall"} for k in ("lo", "hi")}
+    fwall = {k: {"fill_D_bc": "asymmetry", "fill_B_bc": "asymmetry", "fill_phi_bc": "symmetry", "fill_psi_bc": "symmetry",
+                 "fill_mu_bc": "symmetry", "fill_ep_bc": "symmetry"} for k in ("lo", "hi")}
+    for d, f in enumerate(faces):
+        cfg["is_periodic"][d] = int(f == "p")
+        if f == "w":
+            for name, st in cfg["states"].items():
+                st.setdefault("bc", {})["xy"[d]] = fwall if st["type"] == "field" else wall
     return cfg
 
 
-@pytest.mark.parametrize("shape,steps", [((48, 48), 8), ((130, 70), 6), ((256, 256), 20), ((61, 9), 4)])
+@pytest.mark.parametrize("shape,steps,faces", [((48, 48), 8, "pp"), ((130, 70), 6, "pp"), ((256, 256), 20, "pp"), ((61, 9), 4, "pp"),
+                                               ((130, 70), 6, "pw"), ((70, 130), 6, "wp"), ((96, 64), 6, "ww"), ((130, 70), 6, "op"),
+                                               ((96, 64), 6, "wo")])
 @pytest.mark.parametrize("source", ["plasma5", "Lorentz"])
-def test_prologue_matches_oracle_and_separate_launch(oracle, shape, steps, source):
-    cfg = _ot(*shape, source=source)
+def test_prologue_matches_oracle_and_separate_launch(oracle, shape, steps, source, faces):
+    cfg = _ot(*shape, faces=faces, source=source)
     P = config.Problem(cfg, fp_mode=abi.FP_FAST)
     ref = oracle.OracleSim(P, max_grid_size=32)
     dts_ref = ref.run(steps)
@@ -61,11 +73,12 @@ def test_prologue_matches_oracle_and_separate_launch(oracle, shape, steps, sourc
     b.close()
 
 
+@pytest.mark.parametrize("faces", ["pp", "pw", "ww"])
 @pytest.mark.parametrize("device_dt", [True, False])
-def test_prologue_split_launches_and_dt_modes(oracle, device_dt):
+def test_prologue_split_launches_and_dt_modes(oracle, device_dt, faces):
     """interior / frame launches (overlap=2 on an unsplit block) and both time-step modes give what the single
     launch gives, bit for bit: the prologue is pointwise on what each launch loads"""
-    P = config.Problem(_ot(130, 70), fp_mode=abi.FP_FAST)
+    P = config.Problem(_ot(130, 70, faces=faces), fp_mode=abi.FP_FAST)
     a, b = _gpu(P, overlap=2, device_dt=device_dt), _gpu(P, overlap=0, device_dt=True)
     da, db = a.run(5), b.run(5)
     assert a.last_source_fusion() == 3 and b.last_source_fusion() == 3
@@ -76,11 +89,27 @@ def test_prologue_split_launches_and_dt_modes(oracle, device_dt):
     b.close()
 
 
+def test_prologue_on_the_gem_block(oracle):
+    """BASELINE configs[3]: conducting walls in y (reflect_even / reflect_odd ghost cells on every component)"""
+    P = config.Problem(problems.gem_reconnection_2d(128, 64), fp_mode=abi.FP_FAST)
+    ref = oracle.OracleSim(P, max_grid_size=32)
+    ref.run(10)
+    m = _gpu(P)
+    m.run(10)
+    assert m.last_source_fusion() == 3
+    for s in range(m.n_states):
+        assert rel_linf(m.download(s), ref.get_state(s)) <= TOL_FAST, P.state_names[s]
+    m.close()
+
+
 def test_prologue_not_taken_outside_its_cover(oracle):
-    """physical faces (GEM walls), STRICT arithmetic, the implicit solve and 3-D blocks keep stage A a launch of
-    its own — and their results stay what they were"""
+    """STRICT arithmetic, the implicit solve, faces whose ghost cells mix mirror images with copies (a slipwall
+    species beside an outflow field) and 3-D blocks keep stage A a launch of its own — and their results stay what
+    they were"""
+    mixed = _ot(48, 48, faces="pw")
+    del mixed["states"]["field"]["bc"]        # the field falls back to outflow (foextrap) at the species' walls
     cases = [
-        (problems.gem_reconnection_2d(48, 24), abi.FP_FAST, 4),
+        (mixed, abi.FP_FAST, 4),
         (_ot(48, 48), abi.FP_STRICT, 4),
         (_ot(48, 48, solver="implicit"), abi.FP_FAST, 3),
         (problems.richtmyer_meshkov_3d(24, 12, 12), abi.FP_FAST, 3),
