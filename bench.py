@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--extras-512", action="store_true", help="also RMI 512^3 (BASELINE configs[4] at full size; ~2 min of host-side set-up)")
     ap.add_argument("--rehearse", action="store_true",
                     help="diagnostic: run the N-rank path on ONE GPU (all ranks on cuda:0, gloo with host-staged halos); not a measurement")
+    ap.add_argument("--rehearse-fallback", action="store_true",
+                    help="diagnostic, with --rehearse: route halos, dt and barriers through a second gloo group, as the fallback "
+                         "from a failed RCCL pre-flight does")
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2],
                     help="diagnostic: cmfp_set_overlap mode (2 = interior / frame split launches even on an unsplit block)")
     ap.add_argument("--no-corner-transport", action="store_true", help="diagnostic: corner_transport=false (not the headline workload)")
@@ -170,14 +173,63 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     ranks_seen = 1
+    staged_pg = None          # set: halos and the dt word travel through host buffers over this gloo group
+    transport = "none (one rank)"
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        nccl_up = False
+        if not args.rehearse:
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                        timeout=datetime.timedelta(seconds=600))
+                nccl_up = True
+            except Exception as e:       # noqa: BLE001 - the communicator is created eagerly, by all ranks together
+                print(f"[bench rank {rank}] RCCL initialisation failed: {e!r}", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+        if not nccl_up:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+            transport = ("gloo, host-staged (rehearsal on one GPU)" if args.rehearse
+                         else "gloo, host-staged (RCCL initialisation failed)")
+            if args.rehearse_fallback or not args.rehearse:
+                # the plumbing of the fallback below (a second group that carries everything)
+                staged_pg = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        one = torch.ones(1, dtype=torch.int64, device="cpu" if args.rehearse else "cuda")
-        dist.all_reduce(one, op=dist.ReduceOp.SUM)     # the collective backend really spans `world` ranks
+            transport = "RCCL, device buffers"
+            # Pre-flight of exactly what the exchange hooks do (cerberus_amd/mfp.py): a grouped isend / irecv of
+            # device buffers with both ring neighbours and an all-reduce(MIN) of a device double.  The RCCL path
+            # cannot run with more than one rank on the one-GPU boxes this was built on, so if any rank fails here
+            # every rank falls back to host-staged buffers over gloo: a slower transport, still a valid measurement.
+            gloo = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+            ok = 1
+            try:
+                snd = torch.full((1024,), float(rank), dtype=torch.float64, device="cuda")
+                rcv = [torch.empty_like(snd), torch.empty_like(snd)]
+                lo, hi = (rank - 1) % world, (rank + 1) % world
+                if lo == hi:
+                    ops = [dist.P2POp(dist.isend, snd, lo), dist.P2POp(dist.isend, snd, hi),
+                           dist.P2POp(dist.irecv, rcv[1], hi), dist.P2POp(dist.irecv, rcv[0], lo)]
+                else:
+                    ops = [dist.P2POp(dist.isend, snd, lo), dist.P2POp(dist.irecv, rcv[0], lo),
+                           dist.P2POp(dist.isend, snd, hi), dist.P2POp(dist.irecv, rcv[1], hi)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                word = torch.tensor([1.0 + rank], dtype=torch.float64, device="cuda")
+                dist.all_reduce(word, op=dist.ReduceOp.MIN)
+                torch.cuda.synchronize()
+                if float(rcv[0][0].item()) != float(lo) or float(rcv[1][0].item()) != float(hi) or float(word.item()) != 1.0:
+                    raise RuntimeError("RCCL pre-flight: wrong data received")
+            except Exception as e:       # noqa: BLE001 - any failure of the device transport selects the fallback
+                print(f"[bench rank {rank}] RCCL pre-flight failed: {e!r}", file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo)
+            if int(flag.item()) == 0:
+                staged_pg = gloo
+                transport = "gloo, host-staged (RCCL pre-flight failed on at least one rank)"
+        one = torch.ones(1, dtype=torch.int64, device="cpu" if (args.rehearse or staged_pg is not None) else "cuda")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM, group=staged_pg)     # the collective backend really spans `world` ranks
         ranks_seen = int(one.item())
     reps = 1 if args.no_extras else max(1, args.reps)
 
@@ -195,10 +247,12 @@ def main():
         torch.cuda.synchronize()
         return 10 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
+    host_side = args.rehearse or staged_pg is not None
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=staged_pg)
             torch.cuda.synchronize()
 
     def measure(workload, n, fp, steps, warmup, nrep, copy_gbs):
@@ -209,7 +263,7 @@ def main():
         grid = block_grid(dim, world)
         P = build_problem(workload, n, grid, fp_mode, not args.no_corner_transport)
         m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=(3 if args.tiled_hydro else not args.no_fused),
-                exchange_device=("cpu" if args.rehearse and world > 1 else None), overlap=args.overlap)
+                exchange_device=("cpu" if host_side and world > 1 else None), overlap=args.overlap, pg=staged_pg)
         m.init_data()
         m.run(warmup)
         fused = m.last_advance_path()
@@ -226,9 +280,9 @@ def main():
             m.run(steps)
             sync()
             el = time.perf_counter() - t0
-            t = torch.tensor([el], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if host_side else "cuda")
             if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=staged_pg)
             blocks.append(float(t.item()))
         prof = [m.profile_read(s) for s in range(4)]
         m.profile_enable(False)
@@ -325,7 +379,7 @@ def main():
             "value": main_res["value"], "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "reps": reps, "rep_ms_per_step": main_res["rep_ms_per_step"],
-            "ranks_seen": ranks_seen,
+            "ranks_seen": ranks_seen, "halo_transport": transport,
             "config": {"workload": main_res["workload"], "process_grid": main_res["process_grid"],
                        "global_cells": main_res["global_cells"], "fp_mode": args.fp,
                        "fused_kernels": bool(main_res["fused_path"]), "corner_transport": not args.no_corner_transport,
@@ -354,7 +408,7 @@ def main():
             others[f"{w}:{n}"] = {k: r[k] for k in keep if k in r}
         out["other_workloads"] = others
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=staged_pg)
         dist.destroy_process_group()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -42,6 +42,8 @@ def _run(nranks, extra):
     # the rank count of the last leg of the scaling run (process grids 2 x 4 and 2 x 2 x 2)
     (8, ["--workload", "ot2f_2d", "--cells", "256", "--steps", "2", "--warmup", "1"], 256 * 256),
     (8, ["--workload", "rmi_3d", "--cells", "32", "--steps", "2", "--warmup", "1"], 32 ** 3),
+    # the transport bench.py falls back to when its RCCL pre-flight fails: everything through a second gloo group
+    (2, ["--workload", "ot2f_2d", "--cells", "256", "--steps", "2", "--warmup", "1", "--rehearse-fallback"], 256 * 256),
 ])
 def test_bench_n_rank_path(nranks, extra, cells):
     out = _run(nranks, extra)
@@ -60,3 +62,6 @@ def test_bench_n_rank_path(nranks, extra, cells):
     assert len(out["rep_ms_per_step"]) == 2 and out["ms_per_step"] > 0
     assert out["host_ms_per_step"]["exchange"] > 0          # the exchange hook ran on the split block
     assert out["cpu_baseline"] is None                       # rank 0 at N = 1 only
+    assert out["halo_transport"].startswith("gloo")          # the rehearsal's transport (RCCL on the N-GPU node)
+    if out["config"]["workload"].startswith(("ot2f_2d", "gem_2d")):
+        assert out["source_stages"] == {"A": "prologue of the CTU kernels", "C": "epilogue of the field kernel"}
