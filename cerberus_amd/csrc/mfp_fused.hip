@@ -511,12 +511,14 @@ int ctu_march3d(const Geo& g, const StatePhys& sp, const double* Uin, double* Uo
 int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
               const int touches[3][2], int* err, unsigned long long* red, int part, hipStream_t st) {
     const bool tile_only = part & 0x100;
+    const int wrap = part & 0x600;  // in-kernel periodic wrap: the marching kernels only
     part &= 0xff;
     if (g.dim == 3)  // z-marching kernel (mfp_march3d.hip): whole block in one launch
-        return (tile_only || part != 0) ? 0 : ctu_march3d(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, st);
+        return (tile_only || part != 0 || wrap) ? 0 : ctu_march3d(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, st);
     if (g.dim != 2) return 0;
-    if (!tile_only && ctu_march(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, part, st)) return 1;
-    if (!tile_only && ctu_march_field(g, sp, Uin, Uout, do_ctu, dt, touches, nullptr, part, nullptr, st)) return 1;
+    if (!tile_only && ctu_march(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, part | wrap, st)) return 1;
+    if (!tile_only && ctu_march_field(g, sp, Uin, Uout, do_ctu, dt, touches, nullptr, part | wrap, nullptr, st)) return 1;
+    if (wrap) return 0;
 #define HY(R, F)                                                                                                    \
     if (sp.recon == R && sp.flux == F)                                                                              \
         return launch2d<HydroF<R, F>, CMFP_HBX, CMFP_HBY>(g, sp.hp, sp, Uin, Uout, do_ctu, dt, touches, err, red, part, st);
@@ -551,6 +553,7 @@ int ctu_field_src(const Geo& g, const StatePhys& sp, const double* Uin, double* 
                   const int touches[3][2], const SourceEpi& epi, int part, hipStream_t st) {
     if (g.dim != 2 || sp.kind != 1 || epi.a.implicit || epi.a.coll.on) return 0;
     if (!(part & 0x100) && ctu_march_field(g, sp, Uin, Uout, do_ctu, dt, touches, &epi, part, nullptr, st)) return 1;
+    if (part & 0x600) return 0;  // in-kernel periodic wrap: the marching kernel only
     part &= 0xff;
 #define FS(R, NS) \
     if (sp.recon == R && epi.ns == NS) \

@@ -32,8 +32,14 @@ struct MarchRect {
 };
 struct MarchSel {
     int nrect, nwaves, seg;
+    int wrap;  // bit d set: direction d is periodic on this (unsplit) block and the kernel wraps its loads itself
+               // instead of reading ghost cells (then no ghost fill is launched for that direction)
     MarchRect r[4];
 };
+// `part` arguments of the 2-D launchers: low byte 0 / 1 / 2 (all cells / interior / frame), bit 8 the LDS-tiled
+// kernel only, bits 9 and 10 the in-kernel periodic wrap of x and y (marching kernels only)
+static inline int part_wrap(int part) { return (part >> 9) & 3; }
+CMFP_DEV int wrap_index(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
 static inline MarchBC make_march_bc(const StatePhys& sp, const int touches[3][2]) {
     MarchBC b;
@@ -120,6 +126,7 @@ static inline bool march_select(const Geo& g, int part, int ring, int mw, int mu
         seg += seg & 1;  // the kernel runs two rows per loop trip over seg + 2 rows
     }
     sel.seg = seg;
+    sel.wrap = 0;
     sel.nwaves = 0;
     for (int q = 0; q < sel.nrect; ++q) {
         MarchRect& r = sel.r[q];

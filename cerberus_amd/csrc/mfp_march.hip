@@ -70,7 +70,8 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
     const int segi = w / R.ns, strip = w - segi * R.ns;
     const int n0 = g.n[0], n1 = g.n[1];
     const int i = R.ilo + strip * MW - 2 + lane;  // this lane's column (>= -2)
-    const int ic = i < R.ihi + 2 ? i : R.ihi + 2;  // lanes past the rectangle's stencil reach re-read its last column
+    int ic = i < R.ihi + 2 ? i : R.ihi + 2;  // lanes past the rectangle's stencil reach re-read its last column
+    if (sel.wrap & 1) ic = wrap_index(ic, n0);  // periodic in x: the ghost columns are the valid columns of the far side
     const int ja = R.jlo + segi * sel.seg;
     const int jb = (ja + sel.seg - 1 < R.jhi) ? ja + sel.seg - 1 : R.jhi;
     const bool inner = lane >= 2 && lane <= 61;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
     const SourceCoef kf = source_coef(pa, hdt);
 
     auto load_row = [&](int row, double* U) {
+        if (sel.wrap & 2) row = wrap_index(row, n1);
         const long c = col + (long)row * g.sj;
 #pragma unroll
         for (int n = 0; n < 5; ++n) U[n] = Uin[c + n * g.sc];
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
     // what stage A needs beside the species' own values: the other species' momentum, D and B
     auto load_row_pro = [&](int row, double* U) {
         if constexpr (PRO) {
+            if (sel.wrap & 2) row = wrap_index(row, n1);
             const long c = col + (long)row * g.sj;
 #pragma unroll
             for (int n = 0; n < 3; ++n) U[5 + n] = Uoth[c + (1 + n) * g.sc];
@@ -330,7 +333,9 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
     if (g.ng[0] < 2 || g.ng[1] < 2) return 0;
     const bool has_int = g.n[0] >= 5 && g.n[1] >= 5;  // cells whose stencil footprint (+-2) stays inside valid cells
     MarchSel sel;
-    if (Uin[0] && !march_select(g, part, 2, MW, n, sel)) return 1;
+    if (Uin[0] && !march_select(g, part & 0xff, 2, MW, n, sel)) return 1;
+    sel.wrap = part_wrap(part);
+    part &= 0xff;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
     if (pro) {  // the prologue: FAST build, both species in the launch, stage C follows (no reduction here)
 #ifdef CMFP_FASTMATH

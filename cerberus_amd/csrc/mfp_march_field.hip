@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
         const int segi = w / R.ns, strip = w - segi * R.ns;
         const int n0 = g.n[0], n1 = g.n[1];
         const int i = R.ilo + strip * FLD_MW - 4 + lane;  // this lane's column (>= -4)
-        const int ic = i < R.ihi + 4 ? i : R.ihi + 4;      // lanes past the stencil reach re-read the last column
+        int ic = i < R.ihi + 4 ? i : R.ihi + 4;            // lanes past the stencil reach re-read the last column
+        if (sel.wrap & 1) ic = wrap_index(ic, n0);         // periodic in x: the ghost columns are the far side's valid columns
         const int ja = R.jlo + segi * sel.seg;
         const int jb = (ja + sel.seg - 1 < R.jhi) ? ja + sel.seg - 1 : R.jhi;
         const bool upd = lane >= 4 && lane <= 59 && i <= R.ihi;
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
         const double hdt = 0.5 * dt;
         const SourceCoef kf = source_coef(pa, hdt);
         auto load_row = [&](int row, double* U) {
+            if (sel.wrap & 2) row = wrap_index(row, n1);
             const long c = col + (long)row * g.sj;
 #pragma unroll
             for (int n = 0; n < 8; ++n) U[n] = Uin[c + n * g.sc];
@@ -380,7 +382,7 @@ static int fld_wave_slots() {
 int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt,
                     const int touches[3][2], const SourceEpi* epi, int part, const SourcePro* pro, hipStream_t st) {
     static const int off = std::getenv("CMFP_FIELD_MARCH") ? std::atoi(std::getenv("CMFP_FIELD_MARCH")) == 0 : 0;
-    if (off || g.dim != 2 || sp.kind != 1 || !do_ctu || sp.recon != 5 || sp.flux != 10 || !sp.vacuum || part != 0) return 0;
+    if (off || g.dim != 2 || sp.kind != 1 || !do_ctu || sp.recon != 5 || sp.flux != 10 || !sp.vacuum || (part & 0xff) != 0) return 0;
     if (g.ng[0] < 4 || g.ng[1] < 4 || g.n[0] < 1 || g.n[1] < 1) return 0;
     if (epi && (epi->a.implicit || epi->a.coll.on || epi->ns < 1 || epi->ns > 2)) return 0;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
@@ -412,6 +414,7 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
     }
     if (seg > g.n[1]) seg = g.n[1];
     sel.seg = seg;
+    sel.wrap = part_wrap(part);
     R.nseg = (g.n[1] + seg - 1) / seg;
     sel.nwaves = R.ns * R.nseg;
     const MarchBC bc = make_march_bc(sp, touches);

@@ -45,6 +45,7 @@ SYMBOLS = [
     ("cmfp_set_fused", C.c_int, [C.c_void_p, C.c_int]),
     ("cmfp_last_advance_fused", C.c_int, [C.c_void_p]),
     ("cmfp_last_source_fusion", C.c_int, [C.c_void_p]),
+    ("cmfp_last_wrapped_dims", C.c_int, [C.c_void_p]),
     ("cmfp_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("cmfp_profile_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), dp]),
     ("cmfp_set_exchange_callback", C.c_int, [C.c_void_p, EXCHANGE_FN, C.c_void_p]),

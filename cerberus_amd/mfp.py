@@ -232,6 +232,10 @@ class MFP:
         """bit 0: source stage A ran inside the CTU kernels, bit 1: stage C inside the field's (cmfp_last_source_fusion)."""
         return int(self.L.cmfp_last_source_fusion(self.h))
 
+    def last_wrapped_dims(self):
+        """bit d: the last fused step wrapped periodic direction d inside its kernels, no ghost fill (cmfp_last_wrapped_dims)."""
+        return int(self.L.cmfp_last_wrapped_dims(self.h))
+
     def last_error_cell(self):
         """(state index, (i, j, k)) of the first offending cell of the last ERR_PHYSICS, or None where the
         failure left no invalid cell-centred value (cmfp_last_error_cell)."""

@@ -316,6 +316,13 @@ int cmfp_last_advance_fused(const cmfp_context* ctx);
  * Plasma5::calc_time_derivative, MFP_plasma5.cpp:73-244). */
 int cmfp_last_source_fusion(const cmfp_context* ctx);
 
+/* Directions (bit d) of the last fused cmfp_advance whose ghost cells were not filled because the
+ * block spans a periodic direction alone and every CTU state ran on a 2-D marching kernel, which
+ * wraps its loads itself (the periodic part of FillPatch, MFP_action.cpp:59, folded into the
+ * kernels; CMFP_MARCH_WRAP=0 in the environment keeps the fill launches).  The ghost cells of
+ * those directions then hold stale values; cmfp_fill_patch fills them on request.  Diagnostic. */
+int cmfp_last_wrapped_dims(const cmfp_context* ctx);
+
 /* Per-kernel device timing: HIP events recorded on the context's stream around
  * every launch of the fused kernels while enabled (the reference's nearest
  * analogue is its per-box wall-time cost, MFP_CTU_hydro.cpp:143,529-530).
