@@ -94,6 +94,10 @@ struct cmfp_context {
     int src_prologue = 1;      // Strang stage A inside the 2-D marching CTU kernels where that applies (CMFP_SRC_PROLOGUE=0: never)
     int march_wrap = 1;        // periodic directions of an unsplit 2-D block wrapped by the marching kernels, no ghost fill (CMFP_MARCH_WRAP=0: never)
     int last_wrap = 0;         // directions the last fused step wrapped in its kernels (bit d)
+    // cmfp_advance_steps: the fused step leaves its fold of the reduction words here instead of launching it, and
+    // the dt update of the step folds them in the same launch (k_fold_new_dt)
+    bool defer_fold = false, fold_pending = false;
+    RedJobs pending_fold;
     int last_prologue = 0;     // the last fused step ran stage A as the CTU kernels' prologue
     int last_epilogue = 0;     // ... and stage C as the field kernel's epilogue
     int overlap = 1;           // 1: interior flux tiles overlap the halo exchange where the block is split; 2: always split the launches
@@ -1035,7 +1039,20 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     }
     if (overlap) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_int, 0));
     // the CTU kernels' speed slots and, where stage C ran inside the field kernel, its slots: folded by one launch
-    launch_jobs(fold_word, fold_max, &fold_mode);
+    c->fold_pending = false;
+    if (c->defer_fold && !fold_word.empty() && fold_word.size() <= (size_t)RedJobs::MAX) {
+        RedJobs& J = c->pending_fold;
+        std::memset(&J, 0, sizeof(J));
+        for (size_t k = 0; k < fold_word.size(); ++k, ++J.n) {
+            J.slots[J.n] = reinterpret_cast<unsigned long long*>(c->d_part + (size_t)fold_word[k] * CMFP_RED_BLOCKS);
+            J.out[J.n] = c->d_red + fold_word[k];
+            J.is_max[J.n] = fold_max[k];
+            J.mode[J.n] = fold_mode[k];
+        }
+        c->fold_pending = true;
+    } else {
+        launch_jobs(fold_word, fold_max, &fold_mode);
+    }
     for (size_t k = 0; k < fold_word.size(); ++k) {
         c->word_clean[fold_word[k]] = 1;
         if (fold_mode[k] == 0) c->red_valid[fold_word[k]] = 1;
@@ -1594,7 +1611,9 @@ static int advance_steps_on(cmfp_context* c, double dt0, int nsteps, double* dts
     int done = 0, rc = CMFP_OK;
     for (int i = 0; i < nsteps; ++i) {
         std::fill(c->red_valid.begin(), c->red_valid.end(), 0);
+        c->defer_fold = true;
         r = advance_strang_fused(c, 1.0);  // dt arguments become factors of *dtp
+        c->defer_fold = false;
         if (r <= 0) {
             if (r == 0 && i == 0) rc = 1;  // configuration outside the fused kernels: nothing was advanced
             else if (r == 0) rc = fail(c, CMFP_ERR_INVALID, "fused path became unavailable between steps");
@@ -1612,7 +1631,11 @@ static int advance_steps_on(cmfp_context* c, double dt0, int nsteps, double* dts
                 launch_action_dt(c, a, ns + a);
                 c->red_valid[ns + a] = 1;
             }
-        c->L->new_dt(plan, c->d_red, d_dt, d_log, i, c->stream);
+        if (c->fold_pending)
+            c->L->fold_new_dt(c->pending_fold, plan, c->d_red, d_dt, d_log, i, c->stream);
+        else
+            c->L->new_dt(plan, c->d_red, d_dt, d_log, i, c->stream);
+        c->fold_pending = false;
         done = i + 1;
         if (split_any && c->dt_reduce(c->dt_reduce_user, c, d_dt)) {
             rc = fail(c, CMFP_ERR_INVALID, "dt reduce callback failed");

@@ -633,15 +633,13 @@ __global__ void k_reduce_final(const double* __restrict__ part, int nb, int is_m
     }
 }
 
-// one workgroup per job of a RedJobs: fold the 256 atomic slots of a reduction word and reset them
-__global__ __launch_bounds__(256) void k_reduce_many(RedJobs J) {
-    const int job = blockIdx.x;
+// fold the 256 atomic slots of job `job` of a RedJobs and reset them; every thread of a 256-thread workgroup calls it
+__device__ __forceinline__ void reduce_job(const RedJobs& J, int job, double* sh) {
     unsigned long long* const slots = J.slots[job];
     const int is_max = J.is_max[job];
     const unsigned long long identity = is_max ? 0ull : ~0ull;
     if (J.mode[job] == 0) {
         double v = __longlong_as_double((long long)slots[threadIdx.x]);
-        __shared__ double sh[4];
         v = is_max ? wave_max(v) : wave_min(v);  // fmax / fmin: the all-ones NaN of an untouched slot is ignored
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
         __syncthreads();
@@ -653,6 +651,11 @@ __global__ __launch_bounds__(256) void k_reduce_many(RedJobs J) {
         }
     }
     slots[threadIdx.x] = identity;
+}
+// one workgroup per job of a RedJobs
+__global__ __launch_bounds__(256) void k_reduce_many(RedJobs J) {
+    __shared__ double sh[4];
+    reduce_job(J, blockIdx.x, sh);
 }
 // post-mortem of a failed step: the first valid cell (in memory order) of a hydro state without valid primitives
 __global__ void k_first_invalid(Geo g, IBox box, HydroParams hp, const double* __restrict__ U, unsigned long long* out) {
@@ -1418,9 +1421,7 @@ static int l_ctu_gather(const Geo& g, const StatePhys& sp, const double* Uin, do
 // MFP::estTimeStep (MFP_timestep.cpp:4-21: cfl * min over states and actions) and the growth cap of
 // MFP::computeNewDt (:86-93) on the device; the same expressions as the host path of
 // cmfp_est_time_step / cmfp_compute_new_dt
-__global__ void k_new_dt(DtPlan p, const unsigned long long* __restrict__ red, double* __restrict__ dt, double* __restrict__ log,
-                         int idx) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void new_dt_body(const DtPlan& p, const unsigned long long* red, double* dt, double* log, int idx) {
     double est = DBL_MAX;
     for (int n = 0; n < p.n; ++n) {
         double d;
@@ -1441,6 +1442,23 @@ __global__ void k_new_dt(DtPlan p, const unsigned long long* __restrict__ red, d
     log[idx] = old;
     dt[0] = std_min(est, 1.1 * old);
 }
+__global__ void k_new_dt(DtPlan p, const unsigned long long* red, double* dt, double* log, int idx) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    new_dt_body(p, red, dt, log, idx);
+}
+// the step's fold of the reduction words (k_reduce_many) and the dt update in one launch: one workgroup folds the
+// jobs one after the other, then its first thread — which wrote the folded words — applies estTimeStep / computeNewDt
+__global__ __launch_bounds__(256) void k_fold_new_dt(RedJobs J, DtPlan p, const unsigned long long* red, double* dt, double* log, int idx) {
+    __shared__ double sh[4];
+    for (int job = 0; job < J.n; ++job) {
+        reduce_job(J, job, sh);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) new_dt_body(p, red, dt, log, idx);
+}
+static void l_fold_new_dt(const RedJobs& J, const DtPlan& p, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t st) {
+    hipLaunchKernelGGL(k_fold_new_dt, dim3(1), dim3(256), 0, st, J, p, red, dt, log, idx);
+}
 static void l_new_dt(const DtPlan& p, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t st) {
     hipLaunchKernelGGL(k_new_dt, dim3(1), dim3(64), 0, st, p, red, dt, log, idx);
 }
@@ -1454,7 +1472,7 @@ const Launchers* launchers() {
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack, l_fill_multi,
                                 ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, ctu_field_src, ctu_interior, ctu_march2, ctu_march_field, field_vacuum_check, l_source_coef, l_source_fused_box, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
-                                l_leaf_prim2cons, l_reduce_final, l_reduce_many, l_first_invalid, l_new_dt};
+                                l_leaf_prim2cons, l_reduce_final, l_reduce_many, l_first_invalid, l_new_dt, l_fold_new_dt};
     return &L;
 }
 

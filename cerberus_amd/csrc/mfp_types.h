@@ -251,6 +251,8 @@ struct Launchers {
     void (*first_invalid)(const Geo&, const StatePhys&, const double* U, unsigned long long* out, hipStream_t);
     // MFP::estTimeStep + computeNewDt on the device: log[idx] = dt[0]; dt[0] = min(cfl * est, 1.1 * dt[0])
     void (*new_dt)(const DtPlan&, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t);
+    // reduce_many (at most RedJobs::MAX jobs, one workgroup) followed by new_dt, in one launch
+    void (*fold_new_dt)(const RedJobs&, const DtPlan&, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t);
 };
 
 }  // namespace cmfp
