@@ -934,7 +934,11 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     int wrap_flag = 0;
     if (c->march_wrap && c->fused == 1 && c->g.dim == 2) {
         for (int d = 0; d < 2; ++d)
-            if (!c->split[d] && c->geom.is_periodic[d]) wrap_flag |= 0x200 << d;
+            if (!c->split[d] && c->geom.is_periodic[d] && (c->march_wrap == 1 || ((c->march_wrap >> 1) >> d) & 1)) wrap_flag |= 0x200 << d;
+        // Measured (tools/ab_wrap.sh): wrapping y is free at every size; wrapping x costs the single-round field
+        // kernel 0.17 ms at 4096^2 and 0.03 ms at 3072^2 (nothing at 2048^2 or on the 4096 x 2048 GEM block), more
+        // than the fill launch it saves: x is wrapped on blocks of up to 2^23 cells, where launch gaps matter
+        if (c->march_wrap == 1 && (long)c->g.n[0] * c->g.n[1] > (1L << 23)) wrap_flag &= ~0x200;
         for (size_t q = 0; q < list.size() && wrap_flag; ++q) {
             const StatePhys& sp = c->states[list[q]].sp;
             bool ok = tiled[list[q]] != 0;
@@ -996,7 +1000,8 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         // ghost cells of every CTU state (stage B FillPatch, MFP_advance.cpp:209); the flux kernels
         // write the ping-pong partners, so all fills can go first
         int r;
-        if ((r = fill_patch_many(c, list, wrap_flag >> 9))) return r;
+        static const bool keep_fill = std::getenv("CMFP_WRAP_KEEPFILL") != nullptr;  // diagnostic
+        if ((r = fill_patch_many(c, list, keep_fill ? 0 : wrap_flag >> 9))) return r;
     }
     if (src_split) {
         // the interior of stage A goes to the device after the packs and the exchange have been enqueued:
@@ -1159,7 +1164,7 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     c->stream = (hipStream_t)stream;
     if (const char* e = std::getenv("CMFP_SRC_EPILOGUE")) c->src_epilogue = std::atoi(e) != 0;
     if (const char* e = std::getenv("CMFP_SRC_PROLOGUE")) c->src_prologue = std::atoi(e) != 0;
-    if (const char* e = std::getenv("CMFP_MARCH_WRAP")) c->march_wrap = std::atoi(e) != 0;
+    if (const char* e = std::getenv("CMFP_MARCH_WRAP")) c->march_wrap = std::atoi(e);  // 0: never; 1: where it applies; 2 / 4: x / y only (diagnostic)
     c->L = params->fp_mode == CMFP_FP_FAST ? fast::launchers() : strict::launchers();
     c->nsteps = params->time_integrator == CMFP_TI_EULER ? 1 : 2;  // MFP_config.cpp:73-81
     HIPCHK(c, hipSetDevice(device));
