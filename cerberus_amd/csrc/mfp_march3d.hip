@@ -137,17 +137,42 @@ __global__ __launch_bounds__(256, 2) void k_ctu3d(Geo g, March3States<Phys> S, d
     for (int n = 0; n < 15; ++n) stash[n][tid] = 0.0;
     double red_speed = 2.2250738585072014e-308;  // std::numeric_limits<Real>::min(), MFP_eulerian.cpp:265
 
+    // Plane m + 1 enters during iteration m without a barrier of its own: every thread converts the cell of its own
+    // column (kept in registers as Qc: the z stencil) and the first 68 threads one cell each of the tile's outer ring
+    // (18 x 18 - 16 x 16); the loads are issued at the top of the iteration and consumed after the in-plane
+    // reconstruction, which hides their latency.  The tile of plane m + 1 replaces that of plane m - 1, last read
+    // before the first barrier of iteration m - 1, and is first read (as the in-plane stencil) in iteration m + 1,
+    // behind the barriers of iteration m.
+    int rpx = 0, rpy = 0;  // this thread's ring cell (tid < 68)
+    if (tid < PX) rpx = tid, rpy = 0;
+    else if (tid < 2 * PX) rpx = tid - PX, rpy = PY - 1;
+    else rpx = ((tid - 2 * PX) & 1) ? PX - 1 : 0, rpy = 1 + ((tid - 2 * PX) >> 1);
+    const bool ring = tid < NP - C && i0 - 2 + rpx <= n0 + 1 && j0 - 2 + rpy <= n1 + 1;
+    const bool own_in = i <= n0 + 1 && j <= n1 + 1;  // i, j >= -1 always
+    // byte offsets inside the first (ghost) plane of a component (32 bits: cmfp_create keeps a component array below 4 GiB);
+    // the component and plane offsets are wave-uniform and stay in scalar registers
+    const unsigned o_own = (unsigned)(g.at(own_in ? i : 0, own_in ? j : 0, -g.ng[2]) * 8);
+    const unsigned o_ring = (unsigned)(g.at(ring ? i0 - 2 + rpx : 0, ring ? j0 - 2 + rpy : 0, -g.ng[2]) * 8);
+    const int t_ring = rpy * PX + rpx;
+    auto ld = [](const double* base, unsigned off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off); };
+    auto st_ = [](double* base, unsigned off, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off) = v; };
+
     for (int m = ka - 1; m <= kb + 1; ++m) {
-        __syncthreads();  // everyone is done with the buffer of plane m - 1 (and with bufR / Fb)
-        fill_plane(m + 1);
-        __syncthreads();
-        double Qc[5];
+        double Uo[5], Ur[5];
+        {
+            const double* pl = Uin + (long)(m + 1 + g.ng[2]) * g.sk;
 #pragma unroll
-        for (int n = 0; n < 5; ++n) Qc[n] = Pq[(m + 1) & 1][n][pc];
+            for (int n = 0; n < 5; ++n) Uo[n] = ld(pl + n * g.sc, o_own);
+            if (tid < NP - C) {
+#pragma unroll
+                for (int n = 0; n < 5; ++n) Ur[n] = ld(pl + n * g.sc, o_ring);
+            }
+        }
         const double(*Pm)[NP] = Pq[m & 1];
 
         // ---- reconstruction + half-step trace of plane m in x, y, z
         double xlo[5], xhi[5], ylo[5], yhi[5], zlo[5], zhi[5];
+        double Qc[5] = {1.0, 0.0, 0.0, 0.0, 1.0};  // (threads outside the loaded tile: a valid state, never used for a stored value)
         {
             double centre[5], speed[3], st[3][5];
 #pragma unroll
@@ -171,6 +196,23 @@ __global__ __launch_bounds__(256, 2) void k_ctu3d(Geo g, March3States<Phys> S, d
             hydro_cell_faces<RECON>(gamma, st, ylo, yhi);
 #pragma unroll
             for (int n = 0; n < 5; ++n) trace_faces(speed[1], hy, centre[n], ylo[n], yhi[n]);
+            // ---- plane m + 1: conserved -> {rho, u, v, w, eps} of the own column and of one ring cell
+            {
+                double(*dst)[NP] = Pq[(m + 1) & 1];
+                if (own_in) {
+                    if (!Phys::cons2prim(P, Uo, Qc)) bad = true;
+                    Qc[H_P] = f_div(Qc[H_P], gm1);  // MFP_hydro.cpp:847-862
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) dst[n][pc] = Qc[n];
+                }
+                if (ring) {
+                    double Q[5];
+                    if (!Phys::cons2prim(P, Ur, Q)) bad = true;
+                    Q[H_P] = f_div(Q[H_P], gm1);
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) dst[n][t_ring] = Q[n];
+                }
+            }
 #pragma unroll
             for (int n = 0; n < 5; ++n) {
                 st[0][n] = Qa[n];
@@ -303,6 +345,13 @@ __global__ __launch_bounds__(256, 2) void k_ctu3d(Geo g, March3States<Phys> S, d
                     if (bc.rule[1][1][n]) R[n] = bc.rule[1][1][n] == FILL_ODD ? -L[n] : L[n];
             }
             Phys::riemann(P, 1, L, R, fy2);
+            // what the update of plane m - 1 starts from: requested before the barrier, which hides most of the latency
+            double Uold[5] = {0, 0, 0, 0, 0};
+            if (own) {
+                const double* pl = Uin + (long)(m - 1 + g.ng[2]) * g.sk;
+#pragma unroll
+                for (int n = 0; n < 5; ++n) Uold[n] = ld(pl + n * g.sc, o_own);
+            }
             double fx2h[5];
 #pragma unroll
             for (int n = 0; n < 5; ++n) {
@@ -312,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void k_ctu3d(Geo g, March3States<Phys> S, d
             __syncthreads();
             // ---- divergence of plane m - 1 (calc_divergence MFP_eulerian.cpp:1614-1662), new += dU
             if (own) {
-                const long c = g.at(i, j, m - 1);
+                double* po = Uout + (long)(m - 1 + g.ng[2]) * g.sk;
                 double Unew[5];
 #pragma unroll
                 for (int n = 0; n < 5; ++n) {
@@ -320,8 +369,8 @@ __global__ __launch_bounds__(256, 2) void k_ctu3d(Geo g, March3States<Phys> S, d
                     du += dtdx * (fx2[n] - fx2h[n]);
                     du += dtdy * (fy2[n] - Fb[n][tid + BX]);
                     du += dtdz * (fz2_p[n] - fz2[n]);
-                    Unew[n] = Uin[c + n * g.sc] + du;
-                    Uout[c + n * g.sc] = Unew[n];
+                    Unew[n] = Uold[n] + du;
+                    st_(po + n * g.sc, o_own, Unew[n]);
                 }
                 if constexpr (REDUCE) {  // EulerianState::get_allowed_time_step MFP_eulerian.cpp:290-296
                     double s[3];
