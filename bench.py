@@ -28,8 +28,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES = {"ot2f_2d": 320, "kh_2d": 80, "rmi_3d": 320, "gem_2d": 320}   # 2 x 8 B x Ncomp per cell-update
+ALGO_BYTES = {"ot2f_2d": 320, "ot2f_2d_implicit": 320, "kh_2d": 80, "rmi_3d": 320, "gem_2d": 320}   # 2 x 8 B x Ncomp per cell-update
 WORKLOAD_NOTE = {"ot2f_2d": "BASELINE configs[2]: 2D two-fluid Orszag-Tang, plasma5 source",
+                 "ot2f_2d_implicit": "BASELINE configs[2], second series: plasma5 solver = 'implicit' (per-cell 9 x 9 solve)",
                  "kh_2d": "BASELINE configs[1]: 2D KH hydro HLLC",
                  "rmi_3d": "BASELINE configs[4]: 3D two-fluid Richtmyer-Meshkov, plasma5 source",
                  "gem_2d": "BASELINE configs[3]: 2D GEM reconnection two-fluid + Maxwell, walls in y; 8 GPUs x 4096x2048 = 8192^2"}
@@ -49,6 +50,8 @@ def build_problem(workload, n, grid, fp_mode, corner_transport=True):
     from cerberus_amd import config, problems
     if workload == "ot2f_2d":
         cfg = problems.orszag_tang_two_fluid_2d(n)
+    elif workload == "ot2f_2d_implicit":
+        cfg = problems.orszag_tang_two_fluid_2d(n, solver="implicit")
     elif workload == "kh_2d":
         cfg = problems.kelvin_helmholtz_2d(n)
     elif workload == "rmi_3d":
@@ -398,7 +401,7 @@ def main():
         r = measure(args.workload, args.n, other_fp, max(5, args.steps // 2), 2, 3, copy_gbs)
         out[other_fp] = {k: r[k] for k in keep if k in r}
         others = {}
-        legs = [("kh_2d", 2048, 40), ("gem_2d", 4096, 10), ("rmi_3d", 256, 5)]
+        legs = [("kh_2d", 2048, 40), ("gem_2d", 4096, 10), ("rmi_3d", 256, 5), ("ot2f_2d_implicit", 4096, 6)]
         if args.extras_512:
             legs.append(("rmi_3d", 512, 3))
         for w, n, st in legs:

@@ -88,7 +88,7 @@ def _free_port():
                                                  (8, "ot512", True), (8, "ot96", True), (8, "gem64", True), (8, "rmi3d24", True),
                                                  # FAST arithmetic: source stage A as the CTU kernels' prologue on split blocks
                                                  (2, "ot96@fast", True), (4, "ot96@fast", False), (4, "ot512@fast", True), (8, "ot512@fast", True),
-                                                 (4, "gem@fast", True), (4, "rmi3d24@fast", True)] +
+                                                 (4, "gem@fast", True), (8, "gem64@fast", True), (4, "rmi3d24@fast", True)] +
                                                 [(2 + 2 * (k % 2), f"rand{k}", k % 3 != 0) for k in range(10)])
 def test_decomposed_run_equals_single_rank(world, which, batched):
     import torch.multiprocessing as mp
@@ -119,7 +119,10 @@ def test_decomposed_run_equals_single_rank(world, which, batched):
         assert fusion == 3
     for r in range(world):
         o = ret[r]
-        assert o["dts"] == dts
+        if which == "gem64@fast":
+            np.testing.assert_allclose(o["dts"], dts, rtol=1e-13)
+        else:
+            assert o["dts"] == dts
         assert o["fusion"] == fusion
         if not which.startswith("rand"):
             assert o["fused"] == (which.split("@")[0] != "inflow")
@@ -127,7 +130,14 @@ def test_decomposed_run_equals_single_rank(world, which, batched):
         lo, n = o["lo"], o["n"]
         for s in range(len(full)):
             ref = full[s][:, lo[2]:lo[2] + n[2], lo[1]:lo[1] + n[1], lo[0]:lo[0] + n[0]]
-            assert np.array_equal(o["data"][s], ref), (r, s)
+            if which == "gem64@fast":
+                # Ranks without a physical face run the kernel instances without the face rules, the single-rank run
+                # the instances with them; in FAST arithmetic the compiler contracts the two differently (STRICT never
+                # contracts: bit-identical above).  Held to rounding instead.
+                den = np.abs(ref).max() or 1.0
+                assert np.abs(o["data"][s] - ref).max() / den <= 1e-13, (r, s)
+            else:
+                assert np.array_equal(o["data"][s], ref), (r, s)
 
 
 def _nccl_worker(port, ret):
