@@ -661,7 +661,15 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
                 const StatePhys& sp = c->states[A.states[i]].sp;
                 if (sp.kind == CMFP_STATE_HYDRO && sp.visc.kind) return 0;  // viscous fluxes: stage-by-stage kernels only
                 if (sp.kind == CMFP_STATE_HYDRO && sp.hp.nt) return 0;      // passive scalars: stage-by-stage kernels only
-                if (c->states[A.states[i]].has_tables) return 0;            // Dirichlet face data: stage-by-stage kernels only
+                if (c->states[A.states[i]].has_tables) {  // Dirichlet face data: the 2-D hydro marching kernel, else stage by stage
+                    MarchTab none_tab;
+                    std::memset(&none_tab, 0, sizeof(none_tab));
+                    if (c->fused != 1 || !c->L->ctu_march_tab(c->g, sp, nullptr, nullptr, A.corner_transport, dt, c->touches, nullptr,
+                                                              nullptr, 0, none_tab, c->stream))
+                        return 0;
+                    tiled[A.states[i]] = 1;
+                    continue;
+                }
                 if (c->fused != 2 && c->L->ctu_fused(c->g, sp, nullptr, nullptr, A.corner_transport, dt, c->touches, nullptr,
                                                      nullptr, 0 | tile_flag, c->stream)) {
                     tiled[A.states[i]] = 1;
@@ -694,12 +702,28 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     // ranks and they will not (3-D: the marching kernels take the whole block), stage A is split instead:
     // the frame of cells within ng of a face first - every ghost fill reads only those - then the interior
     // on a second stream while the ghost layers are packed, exchanged and unpacked.
+    // one fused CTU launch of state list[q] (in == nullptr: coverage probe): the marching kernel with Dirichlet
+    // face data where the state has tables, else whatever ctu_fused selects
+    bool any_tables = false;
+    for (int v : list) any_tables = any_tables || c->states[v].has_tables;
+    auto ctu_launch = [&](size_t q, const double* in, double* out, unsigned long long* red, int part, hipStream_t st) -> int {
+        const StateRT& s = c->states[list[q]];
+        if (!s.has_tables) return c->L->ctu_fused(c->g, s.sp, in, out, ctu_flag[q], dt, c->touches, c->d_err, red, part, st);
+        MarchTab t;
+        std::memset(&t, 0, sizeof(t));
+        for (int d = 0; d < 2; ++d)
+            for (int side = 0; side < 2; ++side)
+                for (int n = 0; n < 5; ++n) {
+                    t.cell[d][side][n] = s.tab_cell[d][side][n];
+                    t.face[d][side][n] = s.tab_face[d][side][n];
+                }
+        return c->L->ctu_march_tab(c->g, s.sp, in, out, ctu_flag[q], dt, c->touches, c->d_err, red, part & ~0x100, t, st);
+    };
     bool split_any = false;
     for (int d = 0; d < c->g.dim; ++d) split_any = split_any || c->split[d];
     bool overlap = c->overlap == 2 || (c->overlap == 1 && split_any);
     for (size_t q = 0; q < list.size() && overlap; ++q)
-        overlap = tiled[list[q]] && c->L->ctu_fused(c->g, c->states[list[q]].sp, nullptr, nullptr, ctu_flag[q], dt, c->touches,
-                                                    nullptr, nullptr, 1 | tile_flag, c->stream);
+        overlap = tiled[list[q]] && ctu_launch(q, nullptr, nullptr, nullptr, 1 | tile_flag, c->stream);
     if ((overlap || (src >= 0 && split_any && c->overlap != 0)) && !c->stream2) {
         if (c->no_alloc)
             return fail(c, CMFP_ERR_INVALID, "cmfp_advance_steps_static: the overlap stream does not exist yet; run one cmfp_advance first");
@@ -771,7 +795,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     SourcePro pro;
     std::memset(&pro, 0, sizeof(pro));
     if (epi_q >= 0 && c->src_prologue && c->params.fp_mode == CMFP_FP_FAST && c->g.dim == 2 && epi.ns == 2 && !tile_flag &&
-        list.size() == 3) {
+        list.size() == 3 && !any_tables) {  // (ghost cells with Dirichlet data are not copies of valid cells)
         const cmfp_action_desc& SA = c->actions[src];
         size_t qs[2] = {0, 0};
         int found = 0;
@@ -946,8 +970,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
                 ok = ok && (!overlap || field_whole || pro.on) &&
                      c->L->ctu_march_field(c->g, sp, nullptr, nullptr, ctu_flag[q], dt, c->touches, &epi, 0 | wrap_flag, nullptr, c->stream) != 0;
             else
-                ok = ok && c->L->ctu_fused(c->g, sp, nullptr, nullptr, ctu_flag[q], dt, c->touches, nullptr, nullptr,
-                                           (overlap ? 1 : 0) | wrap_flag, c->stream) != 0;
+                ok = ok && ctu_launch(q, nullptr, nullptr, nullptr, (overlap ? 1 : 0) | wrap_flag, c->stream) != 0;
             if (!ok) wrap_flag = 0;
         }
     }
@@ -958,6 +981,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     auto pair_launch = [&](size_t qa, size_t qb, int part, hipStream_t st) -> bool {
         if (tile_flag || (int)qa == epi_q || (int)qb == epi_q || !tiled[list[qa]] || !tiled[list[qb]] || ctu_flag[qa] != ctu_flag[qb])
             return false;
+        if (c->states[list[qa]].has_tables || c->states[list[qb]].has_tables) return false;
         StateRT &a = c->states[list[qa]], &b = c->states[list[qb]];
         const StatePhys* const sp[2] = {&a.sp, &b.sp};
         const double* const in[2] = {a.new_data, b.new_data};
@@ -992,7 +1016,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
             else if (pro.on)
                 return fail(c, CMFP_ERR_INVALID, "source prologue: the paired hydro launch was refused after its probe succeeded");
             else
-                c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q], 1 | tile_flag | wrap_flag, c->stream2);
+                ctu_launch(q, s.new_data, s.alt, slots[q], 1 | tile_flag | wrap_flag, c->stream2);
         }
         HIPCHK(c, hipEventRecord(c->ev_int, c->stream2));
     }
@@ -1034,8 +1058,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         else if (pro.on)
             return fail(c, CMFP_ERR_INVALID, "source prologue: the paired hydro launch was refused after its probe succeeded");
         else if (tiled[list[q]])
-            c->L->ctu_fused(c->g, s.sp, s.new_data, s.alt, ctu_flag[q], dt, c->touches, c->d_err, slots[q],
-                            (overlap ? 2 : 0) | tile_flag | wrap_flag, c->stream);
+            ctu_launch(q, s.new_data, s.alt, slots[q], (overlap ? 2 : 0) | tile_flag | wrap_flag, c->stream);
         else if (f3d[list[q]])
             c->L->ctu_field3d(c->g, s.sp, s.new_data, s.alt, F1, c->gF2[0], ctu_flag[q], dt, c->touches, (int)q == epi_q ? &epi : nullptr,
                               c->stream);

@@ -1412,6 +1412,8 @@ int ctu_interior(const Geo&, const StatePhys&, int do_ctu, int flags, IBox* box)
 // defined in mfp_march.hip
 int ctu_march2(const Geo&, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2], int do_ctu, double dt,
                const int touches[3][2], int* err, unsigned long long* const red[2], int part, const SourcePro* pro, hipStream_t);
+int ctu_march_tab(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt, const int touches[3][2],
+                  int* err, unsigned long long* red, int part, const MarchTab& tab, hipStream_t);
 static int l_ctu_gather(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
                         int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
     if (g.dim == 1) return ctu_gather_1(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);
@@ -1472,7 +1474,7 @@ const Launchers* launchers() {
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack, l_fill_multi,
                                 ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, ctu_field_src, ctu_interior, ctu_march2, ctu_march_field, field_vacuum_check, l_source_coef, l_source_fused_box, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
-                                l_leaf_prim2cons, l_reduce_final, l_reduce_many, l_first_invalid, l_new_dt, l_fold_new_dt};
+                                l_leaf_prim2cons, l_reduce_final, l_reduce_many, l_first_invalid, l_new_dt, ctu_march_tab, l_fold_new_dt};
     return &L;
 }
 

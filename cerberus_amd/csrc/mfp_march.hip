@@ -44,9 +44,14 @@ struct MarchStates {
 // it is loaded (SourcePro, mfp_source.h): the wave also reads the other species' momentum and D, B of the field
 // (14 values per cell instead of 5) and the stage-A values a row's update starts from are rebuilt from its
 // primitives instead of being read again.  FAST arithmetic only.
-template <class Phys, bool HAS_BC, bool REDUCE, bool PRO>
+// TAB: Dirichlet data on physical faces (MarchTab): the ghost cells beyond such a face get the tabulated primitives
+// in place of their own (EulerianState::update_boundary_cells MFP_eulerian.cpp:435-511), the outside face states the
+// values at the face centres, once before sweep 1 — kept, like the reference keeps them in its face arrays — and
+// again after the fill rules before sweep 2 (face_bc :838-877).  Single-state launches of blocks with physical faces.
+template <class Phys, bool HAS_BC, bool REDUCE, bool PRO, bool TAB = false>
 __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S, double dt, MarchBC bc, int* err, MarchSel sel,
-                                                      SourcePro pro) {
+                                                      SourcePro pro, MarchTab tab) {
+    static_assert(!TAB || (HAS_BC && !PRO), "face tables: blocks with physical faces, no source prologue");
     constexpr int RECON = Phys::RECON;
     static_assert(ReconTraits<RECON>::SL == 3 && Phys::IS_HYDRO, "three-point hydro reconstructions");
     dt = launch_dt(g, dt);  // device-resident time step (cmfp_advance_steps)
@@ -131,6 +136,31 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
             }
         }
         if (!Phys::cons2prim(P, U, Q)) bad = true;
+        if constexpr (TAB) {  // ghost cells of faces with Dirichlet data, in the order of State::get_bc_limits
+            const int gi = i + g.ng[0], gj = row + g.ng[1];
+            if (i < n0 + g.ng[0]) {
+                if (bc.touch[0][0] && i < 0) {
+#pragma unroll
+                    for (int n = 0; n < 5; ++n)
+                        if (tab.cell[0][0][n]) Q[n] = tab.cell[0][0][n][gi + (long)gj * g.ng[0]];
+                }
+                if (bc.touch[0][1] && i >= n0) {
+#pragma unroll
+                    for (int n = 0; n < 5; ++n)
+                        if (tab.cell[0][1][n]) Q[n] = tab.cell[0][1][n][(i - n0) + (long)gj * g.ng[0]];
+                }
+                if (bc.touch[1][0] && row < 0) {
+#pragma unroll
+                    for (int n = 0; n < 5; ++n)
+                        if (tab.cell[1][0][n]) Q[n] = tab.cell[1][0][n][gi + (long)gj * g.ext[0]];
+                }
+                if (bc.touch[1][1] && row >= n1) {
+#pragma unroll
+                    for (int n = 0; n < 5; ++n)
+                        if (tab.cell[1][1][n]) Q[n] = tab.cell[1][1][n][gi + (long)(row - n1) * g.ext[0]];
+                }
+            }
+        }
         Q[H_P] = f_div(Q[H_P], gm1);
     };
 
@@ -207,6 +237,32 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
             for (int n = 0; n < 5; ++n) trace_faces(speed[1], ky, centre[n], ylo[n], yhi[n]);
         }
 
+        if constexpr (TAB) {  // face_bc, do_all = false: the outside states of faces with Dirichlet data (valid face cells)
+            if (r >= 0 && r < n1) {
+                if (bc.touch[0][0] && i == -1) {  // cell -1's high face = L of face 0
+#pragma unroll
+                    for (int n = 0; n < 5; ++n)
+                        if (tab.face[0][0][n]) xhi[n] = tab.face[0][0][n][r + g.ng[1]];
+                }
+                if (bc.touch[0][1] && i == n0) {  // cell n0's low face = R of face n0
+#pragma unroll
+                    for (int n = 0; n < 5; ++n)
+                        if (tab.face[0][1][n]) xlo[n] = tab.face[0][1][n][r + g.ng[1]];
+                }
+            }
+            if (i >= 0 && i < n0) {
+                if (bc.touch[1][0] && r == -1) {
+#pragma unroll
+                    for (int n = 0; n < 5; ++n)
+                        if (tab.face[1][0][n]) yhi[n] = tab.face[1][0][n][i + g.ng[0]];
+                }
+                if (bc.touch[1][1] && r == n1) {
+#pragma unroll
+                    for (int n = 0; n < 5; ++n)
+                        if (tab.face[1][1][n]) ylo[n] = tab.face[1][1][n][i + g.ng[0]];
+                }
+            }
+        }
         // ---- Riemann sweep 1 on the low faces of (i, r)
         double fx[5], fy[5] = {0, 0, 0, 0, 0};
         {
@@ -261,6 +317,20 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
                 for (int n = 0; n < 5; ++n)
                     if (bc.rule[1][1][n]) Rr[n] = bc.rule[1][1][n] == FILL_ODD ? -L[n] : L[n];
             }
+            if constexpr (TAB) {
+                if (i >= 0 && i < n0) {
+                    if (bc.touch[1][0] && r == 0) {
+#pragma unroll
+                        for (int n = 0; n < 5; ++n)
+                            if (tab.face[1][0][n]) L[n] = tab.face[1][0][n][i + g.ng[0]];
+                    }
+                    if (bc.touch[1][1] && r == n1) {
+#pragma unroll
+                        for (int n = 0; n < 5; ++n)
+                            if (tab.face[1][1][n]) Rr[n] = tab.face[1][1][n][i + g.ng[0]];
+                    }
+                }
+            }
             Phys::riemann(P, 1, L, Rr, fy2);
         }
         if (r > ja) {
@@ -279,6 +349,20 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
 #pragma unroll
                 for (int n = 0; n < 5; ++n)
                     if (bc.rule[0][1][n]) Rr[n] = bc.rule[0][1][n] == FILL_ODD ? -L[n] : L[n];
+            }
+            if constexpr (TAB) {
+                if (r - 1 >= 0 && r - 1 < n1) {
+                    if (bc.touch[0][0] && i == 0) {
+#pragma unroll
+                        for (int n = 0; n < 5; ++n)
+                            if (tab.face[0][0][n]) L[n] = tab.face[0][0][n][r - 1 + g.ng[1]];
+                    }
+                    if (bc.touch[0][1] && i == n0) {
+#pragma unroll
+                        for (int n = 0; n < 5; ++n)
+                            if (tab.face[0][1][n]) Rr[n] = tab.face[0][1][n][r - 1 + g.ng[1]];
+                    }
+                }
             }
             Phys::riemann(P, 0, L, Rr, fx2);
             // ---- divergence of row r - 1 (calc_divergence MFP_eulerian.cpp:1614-1662), new += dU
@@ -329,7 +413,7 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
 template <class Phys>
 static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const double* const Uin[2], double* const Uout[2],
                         double dt, const int touches[3][2], int* err, unsigned long long* const red[2], int part, const SourcePro* pro,
-                        hipStream_t st) {
+                        hipStream_t st, const MarchTab* tabs = nullptr) {
     if (g.ng[0] < 2 || g.ng[1] < 2) return 0;
     const bool has_int = g.n[0] >= 5 && g.n[1] >= 5;  // cells whose stencil footprint (+-2) stays inside valid cells
     MarchSel sel;
@@ -344,6 +428,7 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
         return 0;
 #endif
     }
+    if (tabs && (n != 1 || !has_bc || pro)) return 0;  // Dirichlet face data: one state, a block with physical faces, no prologue
     if (!Uin[0]) return part == 1 ? has_int : 1;
     const MarchBC bc = make_march_bc(*sp[0], touches);
     MarchStates<Phys> S;
@@ -358,14 +443,24 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
     const dim3 grid(((sel.nwaves * n + 7) / 8) * 8), block(64);
     SourcePro pr;
     std::memset(&pr, 0, sizeof(pr));
-#define CMFP_LAUNCH(BC, RED) hipLaunchKernelGGL((k_ctu_march<Phys, BC, RED, false>), grid, block, 0, st, g, S, dt, bc, err, sel, pr)
+    MarchTab tb;
+    std::memset(&tb, 0, sizeof(tb));
+    if (tabs) {
+        tb = *tabs;
+        if (red[0])
+            hipLaunchKernelGGL((k_ctu_march<Phys, true, true, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb);
+        else
+            hipLaunchKernelGGL((k_ctu_march<Phys, true, false, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb);
+        return 1;
+    }
+#define CMFP_LAUNCH(BC, RED) hipLaunchKernelGGL((k_ctu_march<Phys, BC, RED, false>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb)
 #ifdef CMFP_FASTMATH
     if (pro) {
         pr = *pro;
         if (has_bc)
-            hipLaunchKernelGGL((k_ctu_march<Phys, true, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr);
+            hipLaunchKernelGGL((k_ctu_march<Phys, true, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb);
         else
-            hipLaunchKernelGGL((k_ctu_march<Phys, false, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr);
+            hipLaunchKernelGGL((k_ctu_march<Phys, false, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb);
         return 1;
     }
 #endif
@@ -391,6 +486,22 @@ int ctu_march(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout
 #define HY(R, F) \
     if (sp.recon == R && sp.flux == F) return launch_march<HydroF<R, F>>(g, 1, sps, in, out, dt, touches, err, reds, part, nullptr, st);
     HY(1, 0) HY(1, 1) HY(1, 2) HY(2, 0) HY(2, 1) HY(2, 2) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)
+#undef HY
+    return 0;
+}
+
+// ctu_march for a state with Dirichlet face data (MarchTab)
+int ctu_march_tab(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, int do_ctu, double dt, const int touches[3][2],
+                  int* err, unsigned long long* red, int part, const MarchTab& tab, hipStream_t st) {
+    if (g.dim != 2 || sp.kind != 0 || !do_ctu || sp.hp.nt) return 0;
+    if (!(touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1])) return 0;
+    const StatePhys* const sps[2] = {&sp, nullptr};
+    const double* const in[2] = {Uin, nullptr};
+    double* const out[2] = {Uout, nullptr};
+    unsigned long long* const reds[2] = {red, nullptr};
+#define HY(R, F) \
+    if (sp.recon == R && sp.flux == F) return launch_march<HydroF<R, F>>(g, 1, sps, in, out, dt, touches, err, reds, part, nullptr, st, &tab);
+    HY(1, 0) HY(1, 1) HY(2, 0) HY(2, 1) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)
 #undef HY
     return 0;
 }

@@ -143,6 +143,14 @@ struct SourcePro {
     unsigned odd_f[2][2];     // field components
 };
 
+// Dirichlet data of the physical faces of a 2-D hydro state as the marching kernel reads it
+// (cmfp_state_set_face_values; null: none): cell[d][side][n] over the ghost slab of that face (full ghosted extent
+// of the other direction, i fastest), face[d][side][n] over the face plane (ghosted extent of the other direction)
+struct MarchTab {
+    const double* cell[2][2][5];
+    const double* face[2][2][5];
+};
+
 // ghost fill rule per component for one (dim, side)
 enum FillRule { FILL_SKIP = 0, FILL_WRAP = 1, FILL_FOEXTRAP = 2, FILL_EVEN = 3, FILL_ODD = 4 };
 struct FillRules {
@@ -251,6 +259,9 @@ struct Launchers {
     void (*first_invalid)(const Geo&, const StatePhys&, const double* U, unsigned long long* out, hipStream_t);
     // MFP::estTimeStep + computeNewDt on the device: log[idx] = dt[0]; dt[0] = min(cfl * est, 1.1 * dt[0])
     void (*new_dt)(const DtPlan&, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t);
+    // ctu_fused for a 2-D hydro state with Dirichlet face data, on the marching kernel (mfp_march.hip); 0: not covered
+    int (*ctu_march_tab)(const Geo&, const StatePhys&, const double* Uin, double* Uout, int do_ctu, double dt, const int touches[3][2],
+                         int* err, unsigned long long* red, int part, const MarchTab& tab, hipStream_t);
     // reduce_many (at most RedJobs::MAX jobs, one workgroup) followed by new_dt, in one launch
     void (*fold_new_dt)(const RedJobs&, const DtPlan&, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t);
 };

@@ -77,6 +77,8 @@ class MFP:
         # with an apply_change action the step is not one enqueue-able unit: per-step driver
         self._device_dt = bool(device_dt) and not self._elliptic
         self._time_bc = [s for s in range(self.n_states) if p.face_values_depend_on_time(s)]
+        if self._time_bc:
+            self._device_dt = False      # the face tables are re-tabulated before every step: per-step driver
         if self._time_bc and p.scheme != "strang":
             raise NotImplementedError("time-dependent boundary functions: 'strang' only (one flux evaluation at t + dt)")
         for s in range(self.n_states):

@@ -125,8 +125,8 @@ def test_decomposed_run_equals_single_rank(world, which, batched):
             assert o["dts"] == dts
         assert o["fusion"] == fusion
         if not which.startswith("rand"):
-            assert o["fused"] == (which.split("@")[0] != "inflow")
-            assert o["device_dt"] == (which.split("@")[0] != "inflow")     # cmfp_advance_steps with the cross-rank dt minimum on the device
+            assert o["fused"]           # (since round 2 also the inflow case: marching kernel with the face tables)
+            assert o["device_dt"]     # cmfp_advance_steps with the cross-rank dt minimum on the device
         lo, n = o["lo"], o["n"]
         for s in range(len(full)):
             ref = full[s][:, lo[2]:lo[2] + n[2], lo[1]:lo[1] + n[1], lo[0]:lo[0] + n[0]]
