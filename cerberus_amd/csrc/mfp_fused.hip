@@ -38,13 +38,13 @@ __device__ unsigned long long g_stamps[16];
 // value of the lane one to the left / right inside a row of 16 lanes (= the x-neighbour thread for
 // BX = 16): DPP row shifts, register to register, no LDS.  Every lane of the wave must execute these.
 CMFP_DEV double from_left(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, false);  // row_shr:1
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, true);  // row_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 CMFP_DEV double from_right(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x101, 0xf, 0xf, false);  // row_shl:1
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x101, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x101, 0xf, 0xf, true);  // row_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x101, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 

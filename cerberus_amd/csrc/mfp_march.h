@@ -7,15 +7,18 @@
 namespace CMFP_NS {
 using namespace cmfp;
 
-// value of the neighbouring lane of the wavefront (wave_shr:1 / wave_shl:1); every lane must execute these
+// value of the neighbouring lane of the wavefront (wave_shr:1 / wave_shl:1); every lane must execute these.
+// bound_ctrl: the lane without a neighbour gets 0 — what it got before from the `old` operand 0, but now the
+// destination does not depend on `old` and the compiler no longer zeroes it in front of every shift (two
+// v_mov per shifted double: 5 % of the instructions of the hydro marching kernel)
 CMFP_DEV double lane_left(double v) {  // lane l <- lane l - 1
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 CMFP_DEV double lane_right(double v) {  // lane l <- lane l + 1
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 

@@ -28,13 +28,13 @@ namespace CMFP_NS {
 // value of the lane one to the left / right inside a row of 16 lanes (the x-neighbour thread): DPP row
 // shifts; every lane of the wave must execute these
 CMFP_DEV double row_left(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, false);  // row_shr:1
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, true);  // row_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 CMFP_DEV double row_right(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x101, 0xf, 0xf, false);  // row_shl:1
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x101, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x101, 0xf, 0xf, true);  // row_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x101, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
