@@ -153,6 +153,13 @@ template <> CMFP_DEV double recon_slope<0>(const double*) { return 0; }
 template <> CMFP_DEV double recon_slope<1>(const double* st) {
     double a = st[1] - st[0];
     double b = st[2] - st[1];
+#ifdef CMFP_FASTMATH
+    // the same function without the reference's comparisons: sign(a) min(|a|, |b|) where a and b have one sign,
+    // else 0 (a zero argument gives a zero either way; only the sign of a zero result can differ)
+    const double m = fmin(fabs(a), fabs(b));
+    const bool same = (__double2hiint(a) ^ __double2hiint(b)) >= 0;
+    return same ? copysign(m, a) : 0.0;
+#endif
     double g = 0.0;
     if ((a >= 0.0) && (b >= 0.0)) {
         g = std_min(a, b);
