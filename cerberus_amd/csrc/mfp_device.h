@@ -411,8 +411,15 @@ CMFP_DEV void hllc_solve(const double* L, const double* R, double gamL, double g
 #endif
         F[0] = fv0 + S_K * (ss0 - sv0);
         F[1] = fv1 + S_K * (ss1 - sv1);
+#ifdef CMFP_FASTMATH
+        // the tangential momentum fluxes are the mass flux times the tangential velocity of the side in use:
+        // rho u v + S_K (coeff v - rho v) = v (rho u + S_K (coeff - rho))
+        F[2] = F[0] * v;
+        F[3] = F[0] * w;
+#else
         F[2] = fv2 + S_K * (ss2 - sv2);
         F[3] = fv3 + S_K * (ss3 - sv3);
+#endif
         F[4] = fv4 + S_K * (ss4 - sv4);
     } else {
         if (aux) {

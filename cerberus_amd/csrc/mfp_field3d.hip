@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256, SRC > 0 ? 2 : 3) void k_f3d_z(Geo g, FieldPara
     const int kc = k > n2 + g.ng[2] - 1 ? n2 + g.ng[2] - 1 : k;  // k >= -1
     const long base = g.at(ic, 0, kc);
     const long sy = g.sj;
-    double src_speed[SRC > 0 ? SRC : 1], src_dt = DBL_MAX;
+    double src_speed[SRC > 0 ? SRC : 1];
+    SrcDt src_dt;
 #pragma unroll
     for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s) src_speed[s] = DBL_MIN;
 

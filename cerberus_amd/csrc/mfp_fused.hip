@@ -331,7 +331,8 @@ __global__ __launch_bounds__(BX* BY, (Phys::IS_HYDRO ? 1024 : 768) / (BX * BY)) 
     STAMP(9);
 
     double red_speed = 2.2250738585072014e-308;  // std::numeric_limits<Real>::min(), MFP_eulerian.cpp:265
-    double src_speed[SRC > 0 ? SRC : 1], src_dt = DBL_MAX;
+    double src_speed[SRC > 0 ? SRC : 1];
+    SrcDt src_dt;
 #pragma unroll
     for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s) src_speed[s] = DBL_MIN;
     // ---- phase 5: divergence (calc_divergence MFP_eulerian.cpp:1614-1662) and new += dU

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
     const int lane = threadIdx.x;
     const int per = (sel.nwaves + 7) >> 3;  // XCD-aware order: neighbouring strips on one XCD
     const int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    double src_speed[SRC > 0 ? SRC : 1], src_dt = DBL_MAX;
+    double src_speed[SRC > 0 ? SRC : 1];
+    SrcDt src_dt;
 #pragma unroll
     for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s) src_speed[s] = DBL_MIN;
     if (w < sel.nwaves) {

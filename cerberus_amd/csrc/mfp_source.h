@@ -103,6 +103,29 @@ CMFP_DEV double cell_plasma_dt(double Larmor, double Debye, double Bx, double By
     return dt;
 }
 
+// The plasma / cyclotron dt limit of the cells one thread has written in a source epilogue.  STRICT: the running
+// minimum of cell_plasma_dt.  FAST: that limit decreases monotonically with rho_s (plasma frequency) and with |B|^2
+// (cyclotron frequency), so the thread keeps the maxima of those and evaluates cell_plasma_dt once at the end —
+// the two roots and four divisions per cell were a sixteenth of the field marching kernel's instructions.
+struct SrcDt {
+#ifdef CMFP_FASTMATH
+    double rho_max[2] = {0.0, 0.0};
+    double b2_max = 0.0;
+#else
+    double dt = DBL_MAX;
+#endif
+};
+template <int NS> CMFP_DEV double src_dt_value(const SourceArgs& a, const SrcDt& acc) {
+#ifdef CMFP_FASTMATH
+    double dt = DBL_MAX;
+    const double b = sqrt(acc.b2_max);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) dt = cell_plasma_dt(a.Larmor, a.Debye, b, 0.0, 0.0, acc.rho_max[s], a.r[s], dt);
+    return dt;
+#else
+    return acc.dt;
+#endif
+}
 
 // One Strang source stage with its inner RK2 (MFP_advance.cpp:146-197 / 235-281) for one cell,
 // explicit plasma5 / Lorentz, the arithmetic of k_source_rk2 in the same order:
@@ -239,17 +262,17 @@ template <int NS> CMFP_DEV void source_epilogue_load(const Geo& g, const SourceE
 }
 template <int NS>
 CMFP_DEV void source_epilogue_cell_pre(const Geo& g, const SourceEpi& epi, double dt, long c, double* Unew, const double (*s0)[5],
-                                       double* src_speed, double& src_dt);
+                                       double* src_speed, SrcDt& src_dt);
 template <int NS>
 CMFP_DEV void source_epilogue_cell(const Geo& g, const SourceEpi& epi, double dt, long c, double* Unew, double* src_speed,
-                                   double& src_dt) {
+                                   SrcDt& src_dt) {
     double s0[NS][5];
     source_epilogue_load<NS>(g, epi, c, s0);
     source_epilogue_cell_pre<NS>(g, epi, dt, c, Unew, s0, src_speed, src_dt);
 }
 template <int NS>
 CMFP_DEV void source_epilogue_cell_pre(const Geo& g, const SourceEpi& epi, double dt, long c, double* Unew, const double (*s0)[5],
-                                       double* src_speed, double& src_dt) {
+                                       double* src_speed, SrcDt& src_dt) {
     const SourceArgs& a = epi.a;
     const double hdt = 0.5 * dt;
     SourceCoef kf{epi.kf[0], epi.kf[1], epi.kf[2]};
@@ -267,8 +290,15 @@ CMFP_DEV void source_epilogue_cell_pre(const Geo& g, const SourceEpi& epi, doubl
         }
         GasP G{1.0, 0.0, a.gamma[s]};
         src_speed[s] = cell_max_speed(G, Un, g.dim, src_speed[s]);
-        if (a.limits_dt) src_dt = cell_plasma_dt(a.Larmor, a.Debye, Unew[F_BX], Unew[F_BY], Unew[F_BZ], Un[0], a.r[s], src_dt);
+#ifdef CMFP_FASTMATH
+        if (a.limits_dt) src_dt.rho_max[s] = fmax(src_dt.rho_max[s], Un[0]);
+#else
+        if (a.limits_dt) src_dt.dt = cell_plasma_dt(a.Larmor, a.Debye, Unew[F_BX], Unew[F_BY], Unew[F_BZ], Un[0], a.r[s], src_dt.dt);
+#endif
     }
+#ifdef CMFP_FASTMATH
+    if (a.limits_dt) src_dt.b2_max = fmax(src_dt.b2_max, Unew[F_BX] * Unew[F_BX] + Unew[F_BY] * Unew[F_BY] + Unew[F_BZ] * Unew[F_BZ]);
+#endif
     if (!a.lorentz_only) {
         Unew[F_DX] = fnew[0];
         Unew[F_DY] = fnew[1];
@@ -287,8 +317,9 @@ CMFP_DEV void source_epilogue_cell_pre(const Geo& g, const SourceEpi& epi, doubl
 // workgroup reduction of the epilogue's CFL quantities and one integer atomic per word on slot `slot`;
 // shr: >= 4 doubles per wave of LDS nobody else uses any more; every thread of the workgroup calls it
 template <int NS>
-CMFP_DEV void source_epilogue_reduce(const SourceEpi& epi, double* src_speed, double src_dt, double* shr, int tid, int nwaves,
+CMFP_DEV void source_epilogue_reduce(const SourceEpi& epi, double* src_speed, const SrcDt& acc, double* shr, int tid, int nwaves,
                                      int slot) {
+    double src_dt = src_dt_value<NS>(epi.a, acc);
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
