@@ -154,11 +154,9 @@ template <> CMFP_DEV double recon_slope<1>(const double* st) {
     double a = st[1] - st[0];
     double b = st[2] - st[1];
 #ifdef CMFP_FASTMATH
-    // the same function without the reference's comparisons: sign(a) min(|a|, |b|) where a and b have one sign,
-    // else 0 (a zero argument gives a zero either way; only the sign of a zero result can differ)
-    const double m = fmin(fabs(a), fabs(b));
-    const bool same = (__double2hiint(a) ^ __double2hiint(b)) >= 0;
-    return same ? copysign(m, a) : 0.0;
+    // the same function without the reference's comparisons and selects: max(0, min(a, b)) + min(0, max(a, b))
+    // (only the sign of a zero result can differ)
+    return fmax(0.0, fmin(a, b)) + fmin(0.0, fmax(a, b));
 #endif
     double g = 0.0;
     if ((a >= 0.0) && (b >= 0.0)) {

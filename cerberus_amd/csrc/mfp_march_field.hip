@@ -43,6 +43,10 @@ static constexpr int FLD_PAD = 8;   // doubles in front of and behind the window
 #define CMFP_FLD_DEPTH 2
 #endif
 static constexpr int FLD_DEPTH = CMFP_FLD_DEPTH;  // iterations a row (and the epilogue's species) is requested ahead of its use
+#ifndef CMFP_FLD_SPDEPTH
+#define CMFP_FLD_SPDEPTH CMFP_FLD_DEPTH
+#endif
+static constexpr int SP_DEPTH = CMFP_FLD_SPDEPTH;  // the same for the epilogue's species alone (they are used at the end of an iteration)
 
 // the O6 interface value between s3 and s4: recon_faces<5>'s `hi` of the cell holding s3 (= `lo` of the next)
 CMFP_DEV double o6_interface(double s1, double s2, double s3, double s4, double s5, double s6) {
@@ -186,13 +190,14 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
                     for (int n = 0; n < NL; ++n) Un[n] = Un2[n];
                     const int rn = r + 5 < jb + 4 ? r + 5 : jb + 4;  // rows past the segment's stencil reach are not touched
                     load_row(rn, Un2);
-                    if constexpr (SRC > 0) {
-                        if (upd && r + 1 >= ja && r + 1 <= jb) source_epilogue_load<SRC>(g, epi, col + (long)(r + 1) * g.sj, sp_nx2);
-                    }
                 } else {
                     const int rn = r + 4 < jb + 4 ? r + 4 : jb + 4;
                     load_row(rn, Un);
-                    if constexpr (SRC > 0) {
+                }
+                if constexpr (SRC > 0) {
+                    if constexpr (SP_DEPTH == 2) {
+                        if (upd && r + 1 >= ja && r + 1 <= jb) source_epilogue_load<SRC>(g, epi, col + (long)(r + 1) * g.sj, sp_nx2);
+                    } else {
                         if (upd && r >= ja && r <= jb) source_epilogue_load<SRC>(g, epi, col + (long)r * g.sj, sp_nxt);
                     }
                 }
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
 #pragma unroll
                     for (int n = 0; n < 5; ++n) {
                         sp_cur[s][n] = sp_nxt[s][n];
-                        if constexpr (FLD_DEPTH == 2) sp_nxt[s][n] = sp_nx2[s][n];
+                        if constexpr (SP_DEPTH == 2) sp_nxt[s][n] = sp_nx2[s][n];
                     }
             }
         };
