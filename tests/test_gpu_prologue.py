@@ -125,3 +125,34 @@ def test_prologue_not_taken_outside_its_cover(oracle):
         for s in range(m.n_states):
             assert rel_linf(m.download(s), ref.get_state(s)) <= TOL_FAST, P.state_names[s]
         m.close()
+
+
+@pytest.mark.parametrize("shape,faces", [((1100, 900), "pp"), ((2048, 520), "pw"), ((520, 2048), "wp")])
+def test_prologue_at_size(shape, faces):
+    """blocks with many strips, long segments and several rounds of waves (no oracle at this size): the prologue
+    against the separate stage-A launch to rounding, and bit-identical with and without the kernels' own periodic
+    wrap and with split launches"""
+    P = config.Problem(_ot(*shape, faces=faces), fp_mode=abi.FP_FAST)
+    a, b = _gpu(P, prologue=True), _gpu(P, prologue=False)
+    da, db = a.run(4), b.run(4)
+    assert a.last_source_fusion() == 3 and b.last_source_fusion() == 2
+    np.testing.assert_allclose(da, db, rtol=1e-13)
+    ua = [a.download(s) for s in range(a.n_states)]
+    for s in range(a.n_states):
+        assert rel_linf(ua[s], b.download(s)) <= TOL_SAME, (P.state_names[s], rel_linf(ua[s], b.download(s)))
+    a.close()
+    b.close()
+    old = os.environ.get("CMFP_MARCH_WRAP")
+    os.environ["CMFP_MARCH_WRAP"] = "0"
+    try:
+        c = _gpu(P, prologue=True, overlap=2)
+    finally:
+        if old is None:
+            del os.environ["CMFP_MARCH_WRAP"]
+        else:
+            os.environ["CMFP_MARCH_WRAP"] = old
+    dc = c.run(4)
+    assert c.last_wrapped_dims() == 0 and dc == da
+    for s in range(c.n_states):
+        assert np.array_equal(c.download(s), ua[s]), P.state_names[s]
+    c.close()
