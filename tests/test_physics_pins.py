@@ -159,6 +159,58 @@ def check_cyclotron(make, B0=0.5):
     return err, untouched
 
 
+# ---- a transverse electromagnetic wave in the plasma: transport and source together -----------------------------
+WAVE_TOL = 5e-4       # amplitude of the standing wave over one period against cos(w t), w^2 = w_p^2 + c^2 k^2: 0.05 % (measured 5e-5)
+
+
+def check_em_wave(make, mode=4, n=128, **kw):
+    """D_y = A cos(k x) on the uniform plasma at rest: the Maxwell fluxes (FieldRH, MFP_field_RH.cpp:29-106, speed
+    `lightspeed`) and the plasma5 source (MFP_plasma5.cpp:123-129, 213-235: current -Larmor / (Debye^2 c) J into D,
+    force (rho r / Larmor) c E on the species) give d^2 D_y / dt^2 = c^2 d^2 D_y / dx^2 - w_p^2 D_y, a standing wave
+    at w^2 = w_p^2 + c^2 k^2 — the cold-plasma dispersion relation, which neither the cavity (no plasma) nor the
+    Langmuir check (no transport) sees."""
+    A = 1e-4
+    k = 2 * math.pi * mode
+    cfg = problems.uniform_plasma_2d(8, "plasma5", u0=0.0, **kw)
+    cfg["n_cell"] = [n, 8]
+    cfg["prob_hi"] = [1.0, 8.0 / n]
+    cfg["states"]["field"]["value"] = {"y_D": lambda d: A * np.cos(k * d["x"])}
+    P = config.Problem(cfg)
+    run = make(P)
+    D = P.ref["Debye"]
+    sp = [(i, cfg["states"][nm]["gas"]) for i, nm in enumerate(P.state_names) if cfg["states"][nm]["type"] == "hydro"]
+    wp2 = sum(float(run.state(i)[0].mean()) * (g["charge"] / g["mass"]) ** 2 for i, g in sp) / (D * D)
+    w = math.sqrt(wp2 + (P.ref["lightspeed"] * k) ** 2)
+    x = (np.arange(n) + 0.5) / n
+    proj = lambda: 2.0 * float((run.state(P.state_index["field"])[1][0] * np.cos(k * x)[None, :]).mean()) / A
+    assert abs(proj() - 1.0) < 1e-12
+    T = 2 * math.pi / w
+    nsteps = 400
+    dt, t, err = T / nsteps, 0.0, 0.0
+    assert dt <= run.est() / P.cfl
+    for _ in range(nsteps):
+        run.advance(dt)
+        t += dt
+        err = max(err, abs(proj() - math.cos(w * t)))
+    run.close()
+    return err, math.sqrt(wp2) / w
+
+
+def test_em_wave_dispersion_oracle(oracle):
+    err, frac = check_em_wave(lambda P: OracleRunner(oracle, P))
+    assert 0.5 < frac < 0.9          # both terms of the dispersion relation matter at this wavenumber
+    assert err <= WAVE_TOL, err
+    err, frac = check_em_wave(lambda P: OracleRunner(oracle, P), mode=2, lightspeed=10.0, skin_depth=0.5, beta=0.3, mass_ratio=100.0)
+    assert err <= WAVE_TOL, (err, frac)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [abi.FP_STRICT, abi.FP_FAST])
+def test_em_wave_dispersion_gpu(mode):
+    err, _ = check_em_wave(lambda P: GpuRunner(config.Problem(P.cfg, fp_mode=mode)))
+    assert err <= WAVE_TOL, err
+
+
 def test_langmuir_oscillation_oracle(oracle):
     err, d_back, uniform = check_langmuir(lambda P: OracleRunner(oracle, P))
     assert err <= OSC_TOL and d_back <= 2 * OSC_TOL and uniform <= 1e-13, (err, d_back, uniform)
