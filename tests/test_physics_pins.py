@@ -98,6 +98,67 @@ def test_cavity_mode_gpu(n, m, l, recon, mode):
     assert err <= tol and back <= 2 * tol and other <= 1e-12, (err, back, other)
 
 
+# ---- divergence-cleaning waves: the (D_x, phi) and (B_x, psi) pairs of FieldRH ------------------------------
+def check_cleaning_wave(make, n=48, m=2, div_transport=1.0, lightspeed=2.0):
+    """A pure divergence error D_x = cos(k x), B_x = cos(k x) / 2 on a periodic field-only block: the cleaning
+    fluxes of FieldRH (MFP_field_RH.cpp:66-75, 94-103: F[Dx] = c0 phi ..., F[phi] = c_h^2 / c0 Dx ...) carry it as a
+    standing wave at the cleaning speed, w = c_h k with c_h = div_transport x lightspeed (MFP_field.cpp:384), and
+    phi = (c_h / c0) sin(k x) sin(w t).  No shipped example sets div_transport, so only this check and the leaf
+    vectors exercise that branch.  Held to the cavity bar where c_h >= c0; with c_h < c0 the reference's half-step
+    trace advances every component with the one speed max(c0, c_h) (MFP_eulerian.cpp:609-676), faster than this
+    wave, and the scheme is first order for it: checked as such below."""
+    k = 2 * math.pi * m
+    cfg = problems.cavity_mode_2d(n, 1, 1)
+    cfg["n_cell"] = [n, 8]
+    cfg["prob_hi"] = [1.0, 8.0 / n]
+    cfg["is_periodic"] = [1, 1]
+    cfg["lightspeed"] = lightspeed
+    cfg["time_integration_scheme"] = "strang"
+    f = cfg["states"]["field"]
+    del f["bc"]
+    f["div_transport"] = div_transport
+    f["value"] = {"x_D": lambda d: np.cos(k * d["x"]), "x_B": lambda d: 0.5 * np.cos(k * d["x"])}
+    P = config.Problem(cfg)
+    run = make(P)
+    ch = div_transport * lightspeed
+    w = ch * k
+    x = (np.arange(n) + 0.5) / n
+    cs, sn = np.cos(k * x)[None, :], np.sin(k * x)[None, :]
+    proj = lambda a, b: 2.0 * float((a * b).mean())
+    T = 2 * math.pi / w
+    dt0 = run.est()
+    nsteps = int(math.ceil(T / dt0))
+    dt, t, err = T / nsteps, 0.0, 0.0
+    for _ in range(nsteps):
+        run.advance(dt)
+        t += dt
+        U = run.state(0)
+        err = max(err, abs(proj(U[0, 0], cs) - math.cos(w * t)), abs(proj(U[3, 0], cs) - 0.5 * math.cos(w * t)),
+                  abs(proj(U[6, 0], sn) - (ch / lightspeed) * math.sin(w * t)),
+                  abs(proj(U[7, 0], sn) - 0.5 * (ch / lightspeed) * math.sin(w * t)))
+    other = max(float(np.abs(run.state(0)[c]).max()) for c in (1, 2, 4, 5))
+    run.close()
+    return err, other
+
+
+def test_cleaning_wave_oracle(oracle):
+    err, other = check_cleaning_wave(lambda P: OracleRunner(oracle, P))
+    assert err <= CAVITY_TOL and other <= 1e-12, (err, other)
+    err, other = check_cleaning_wave(lambda P: OracleRunner(oracle, P), n=64, m=3, div_transport=1.5, lightspeed=1.0)
+    assert err <= CAVITY_TOL and other <= 1e-12, (err, other)
+    # c_h < c0: first-order convergence to the same wave (the single-speed trace, see above)
+    e48, _ = check_cleaning_wave(lambda P: OracleRunner(oracle, P), n=48, div_transport=0.5)
+    e96, _ = check_cleaning_wave(lambda P: OracleRunner(oracle, P), n=96, div_transport=0.5)
+    assert 1.6 <= e48 / e96 <= 2.4 and e96 < 0.12, (e48, e96)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [abi.FP_STRICT, abi.FP_FAST])
+def test_cleaning_wave_gpu(mode):
+    err, other = check_cleaning_wave(lambda P: GpuRunner(config.Problem(P.cfg, fp_mode=mode)))
+    assert err <= CAVITY_TOL and other <= 1e-12, (err, other)
+
+
 # ---- plasma (Langmuir) and cyclotron oscillations --------------------------------------------------------
 OSC_TOL = 5e-4        # normalised current / momentum over one period against the analytic cosine: 0.05 %
 
