@@ -272,6 +272,47 @@ def test_em_wave_dispersion_gpu(mode):
     assert err <= WAVE_TOL, err
 
 
+def check_cleaning_damping(make, damp=2.0, div_transport=1.0):
+    """The damping of the cleaning potentials in plasma5 (MFP_plasma5.cpp:123-129, 225-235): on a uniform, neutral
+    plasma at rest nothing moves and nothing flows, and phi, psi obey d phi / dt = -(c_h^2 / c_d^2) phi with
+    c_d = c_h / div_damping, i.e. decay at the rate div_damping^2 whatever c_h is.  (The charge term of the phi source,
+    f2 rho_c, carries dt twice in the reference — f2 = dt c_h^2 f1 / c with f1 = dt Larmor / (Debye^2 c) — so it has
+    no dt-independent solution to pin; it is reproduced as written and covered by the leaf and N-step vectors.)"""
+    cfg = problems.uniform_plasma_2d(8, "plasma5", u0=0.0)
+    cfg["states"]["field"].update({"div_transport": div_transport, "div_damping": damp})
+    cfg["states"]["field"]["value"] = {"phi": 1.0, "psi": -0.5}
+    P = config.Problem(cfg)
+    run = make(P)
+    rate = damp * damp
+    fs = P.state_index["field"]
+    dt = min(2.0 / rate / 400, run.est() / P.cfl)
+    nsteps = int(math.ceil(2.0 / rate / dt))
+    dt, t, err = 2.0 / rate / nsteps, 0.0, 0.0
+    for _ in range(nsteps):
+        run.advance(dt)
+        t += dt
+        f = run.state(fs)
+        err = max(err, abs(float(f[6].mean()) - math.exp(-rate * t)), abs(float(f[7].mean()) + 0.5 * math.exp(-rate * t)))
+    still = max(float(np.abs(run.state(i)[1:4]).max()) for i in range(len(P.state_names)) if i != fs)
+    flat = max(float(np.ptp(run.state(fs)[c])) for c in (6, 7))
+    run.close()
+    return err, still, flat
+
+
+def test_cleaning_damping_oracle(oracle):
+    err, still, flat = check_cleaning_damping(lambda P: OracleRunner(oracle, P))
+    assert err <= OSC_TOL and still == 0.0 and flat <= 1e-13, (err, still, flat)
+    err, still, flat = check_cleaning_damping(lambda P: OracleRunner(oracle, P), damp=5.0, div_transport=0.5)
+    assert err <= OSC_TOL and still == 0.0 and flat <= 1e-13, (err, still, flat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [abi.FP_STRICT, abi.FP_FAST])
+def test_cleaning_damping_gpu(mode):
+    err, still, flat = check_cleaning_damping(lambda P: GpuRunner(config.Problem(P.cfg, fp_mode=mode)))
+    assert err <= OSC_TOL and still == 0.0 and flat <= 1e-13, (err, still, flat)
+
+
 def test_langmuir_oscillation_oracle(oracle):
     err, d_back, uniform = check_langmuir(lambda P: OracleRunner(oracle, P))
     assert err <= OSC_TOL and d_back <= 2 * OSC_TOL and uniform <= 1e-13, (err, d_back, uniform)
