@@ -73,6 +73,9 @@ class StateDesc(C.Structure):
         ("visc_Pr", C.c_double),
         ("n_tracers", C.c_int),
         ("bc", ((C.c_int * 2) * MAX_DIM) * MAX_COMP),
+        ("mixture", C.c_int),
+        ("species_mass", C.c_double * (MAX_TRACERS + 1)),
+        ("species_gamma", C.c_double * (MAX_TRACERS + 1)),
     ]
 
 

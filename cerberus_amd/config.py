@@ -61,20 +61,64 @@ def gas_n_tracers(gas):
     return len(m) - 1 if isinstance(m, (list, tuple)) else 0
 
 
-def gas_scalar(gas, key):
-    """mass / charge / gamma of the gas.  Lists (several species) are taken where every entry is the
-    same (mass_const, charge_const, gamma_const, MFP_thermally_perfect_gas.cpp:33-35: the tracers are
-    then passive scalars); true mixtures are outside the built path."""
+def gas_list(gas, key):
+    """mass / charge / gamma of every species of the gas (set_values, MFP_thermally_perfect_gas.cpp:24-26)."""
     v = gas[key]
     if isinstance(v, (list, tuple)):
         if len(v) != (gas_n_tracers(gas) + 1):
             raise ValueError("'mass', 'charge' and 'gamma' must have the same number of components")  # :37-40
-        if any(float(x) != float(v[0]) for x in v):
-            raise NotImplementedError("multi-species mixtures with different mass / charge / gamma are not built yet")
         if len(v) - 1 > abi.MAX_TRACERS:
             raise NotImplementedError(f"at most {abi.MAX_TRACERS} tracers")
-        return float(v[0])
-    return float(v)
+        return [float(x) for x in v]
+    return [float(v)] * (gas_n_tracers(gas) + 1)
+
+
+def gas_is_mixture(gas):
+    """True where the species differ in mass or gamma (mass_const / gamma_const false,
+    MFP_thermally_perfect_gas.cpp:32-34): gamma, mass and cp of a cell then follow its mass fractions."""
+    return any(x != v[0] for v in (gas_list(gas, "mass"), gas_list(gas, "gamma")) for x in v)
+
+
+def gas_scalar(gas, key):
+    """mass / charge / gamma of species 0: the constants of the gas where every species has the same
+    (mass_const, charge_const, gamma_const, MFP_thermally_perfect_gas.cpp:33-35: the tracers are then
+    passive scalars).  Species of different charge are read by the sources only, which are not built
+    for mixtures."""
+    v = gas_list(gas, key)
+    if key == "charge" and any(x != v[0] for x in v):
+        raise NotImplementedError("species of different charge (sources of a mixture) are not built")
+    return v[0]
+
+
+def gas_gamma_from_alpha(gas, alpha):
+    """ThermallyPerfectGas::get_gamma_from_prim (MFP_thermally_perfect_gas.cpp:51-83) on arrays:
+    alpha = list of the n_tracers mass-fraction arrays."""
+    g, m = gas_list(gas, "gamma"), gas_list(gas, "mass")
+    if all(x == g[0] for x in g):
+        return g[0]
+    s_cp = s_cv = s_a = 0.0
+    for i, a in enumerate(alpha):
+        a = np.clip(a, 0.0, 1.0)
+        s_a = s_a + a
+        s_cp = s_cp + a * (g[i] / (m[i] * (g[i] - 1.0)))
+        s_cv = s_cv + a * (1.0 / (m[i] * (g[i] - 1.0)))
+    s_cp = s_cp + (1.0 - s_a) * (g[-1] / (m[-1] * (g[-1] - 1.0)))
+    s_cv = s_cv + (1.0 - s_a) * (1.0 / (m[-1] * (g[-1] - 1.0)))
+    return s_cp / s_cv
+
+
+def gas_mass_from_alpha(gas, alpha):
+    """HydroGas::get_mass_from_prim (MFP_hydro_gas.cpp:50-70) on arrays."""
+    m = gas_list(gas, "mass")
+    if all(x == m[0] for x in m):
+        return m[0]
+    s_m = s_a = 0.0
+    for i, a in enumerate(alpha):
+        a = np.clip(a, 0.0, 1.0)
+        s_a = s_a + a
+        s_m = s_m + a / m[i]
+    s_m = s_m + (1.0 - s_a) / m[-1]
+    return 1.0 / s_m
 
 
 class Problem:
@@ -142,6 +186,14 @@ class Problem:
                     raise NotImplementedError("only the thermally_perfect gas is on the built path")
                 d.mass, d.charge, d.gamma = (gas_scalar(gas, k) for k in ("mass", "charge", "gamma"))
                 d.n_tracers = gas_n_tracers(gas)
+                if gas_is_mixture(gas):
+                    d.mixture = 1
+                    for k, x in enumerate(gas_list(gas, "mass")):
+                        d.species_mass[k] = x
+                    for k, x in enumerate(gas_list(gas, "gamma")):
+                        d.species_gamma[k] = x
+                    if sd.get("viscosity"):
+                        raise NotImplementedError("viscous fluxes of a mixture are not built")
                 d.flux = abi.FLUX[sd["flux"]]
                 if d.flux == abi.FLUX["RankineHugoniot"]:
                     raise ValueError("hydro state with a field flux")
@@ -337,8 +389,12 @@ class Problem:
                 out[c] = self._eval(val.get(name), dat, shape, FIELD_DEFAULT.get(name, 0.0))
             return out
         gas = sd["gas"]
-        m, g = gas_scalar(gas, "mass"), gas_scalar(gas, "gamma")
         nt = gas_n_tracers(gas)
+        alpha = val.get("alpha", [])
+        if not isinstance(alpha, (list, tuple)):
+            alpha = [alpha] * nt
+        alpha = [self._eval(alpha[i] if i < len(alpha) else None, dat, shape) for i in range(nt)]
+        m, g = gas_mass_from_alpha(gas, alpha), gas_gamma_from_alpha(gas, alpha)   # get_mass_from_prim, get_gamma_from_prim
         rho = self._eval(val.get("rho"), dat, shape) if "rho" in val else None
         if rho is None and "nd" in val:                       # init_from_number_density, MFP_hydro.cpp:113-120
             rho = self._eval(val["nd"], dat, shape) * m
@@ -358,11 +414,8 @@ class Problem:
         if np.any(rho <= 0) or np.any(p <= 0):
             raise ValueError("Primitive values outside of physical bounds!!")
         out = np.empty((5 + nt,) + shape)
-        alpha = val.get("alpha", [])
-        if not isinstance(alpha, (list, tuple)):
-            alpha = [alpha] * nt
         for i in range(nt):                                   # tracer = alpha * rho, MFP_thermally_perfect_gas.cpp:243-245
-            out[5 + i] = self._eval(alpha[i] if i < len(alpha) else None, dat, shape) * rho
+            out[5 + i] = alpha[i] * rho
         out[0] = rho
         out[1] = u * rho
         out[2] = v * rho

@@ -1254,6 +1254,24 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
                 return fail(c, CMFP_ERR_INVALID, "mass and gamma cannot be 0");  // MFP_thermally_perfect_gas.cpp:29-30
             sp.hp.gas = GasP{states[s].mass, states[s].charge, states[s].gamma};
             sp.hp.shock_threshold = states[s].shock_threshold;
+            sp.hp.mix = 0;
+            if (states[s].mixture) {
+                // species of different mass / gamma (mass_const / gamma_const false, MFP_thermally_perfect_gas.cpp:32-34)
+                const int nsp = states[s].n_tracers + 1;
+                if (states[s].viscosity) return fail(c, CMFP_ERR_INVALID, "viscous fluxes of a mixture are not built");
+                for (int i = 0; i < nsp; ++i) {
+                    const double m = states[s].species_mass[i], gm = states[s].species_gamma[i];
+                    if (!(m != 0.0) || !(gm != 0.0) || gm == 1.0) return fail(c, CMFP_ERR_INVALID, "mass and gamma cannot be 0");
+                    sp.hp.sp_mass[i] = m;
+                    sp.hp.sp_cp[i] = gm / (m * (gm - 1.0));  // cpi, cvi of get_gamma_from_prim (:69-70)
+                    sp.hp.sp_cv[i] = 1.0 / (m * (gm - 1.0));
+                    if (gm != states[s].species_gamma[0]) sp.hp.mix |= 1;
+                    if (m != states[s].species_mass[0]) sp.hp.mix |= 2;
+                }
+                if (states[s].species_mass[0] != states[s].mass || states[s].species_gamma[0] != states[s].gamma)
+                    return fail(c, CMFP_ERR_INVALID, "mixture: mass / gamma must be those of species 0");
+                if (sp.hp.mix) sp.nq = sp.nc + 1;  // the face states' Gamma entry travels with the primitives
+            }
         } else if (sp.kind == CMFP_STATE_FIELD) {
             sp.nc = sp.nq = 10;
             if (sp.flux != CMFP_FLUX_FIELD_RH) return fail(c, CMFP_ERR_INVALID, "field flux must be RankineHugoniot");
@@ -1274,6 +1292,9 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
         for (int i = 0; i < A.n_states; ++i)
             if (A.states[i] < 0 || A.states[i] >= n_states) return fail(c, CMFP_ERR_INVALID, "bad action state index");
         if (A.kind == CMFP_ACTION_CTU) continue;
+        for (int i = 0; i < A.n_states; ++i)
+            if (c->states[A.states[i]].sp.kind == CMFP_STATE_HYDRO && c->states[A.states[i]].sp.hp.mix)
+                return fail(c, CMFP_ERR_INVALID, "source actions on a mixture (per-cell mass / charge) are not built");
         if (A.kind == CMFP_ACTION_COLLISIONS_RAMBO) {
             if (A.n_states > 4) return fail(c, CMFP_ERR_INVALID, "at most 4 species per collisions action");
             for (int i = 0; i < A.n_states; ++i)
@@ -1735,6 +1756,7 @@ int cmfp_state_set_face_values(cmfp_context* c, int s, int dim, int side, int pr
         return fail(c, CMFP_ERR_INVALID, "bad state / face");
     StateRT& st = c->states[s];
     if (prim < 0 || prim >= st.sp.nq) return fail(c, CMFP_ERR_INVALID, "bad primitive index");
+    if (st.sp.kind == CMFP_STATE_HYDRO && st.sp.hp.mix) return fail(c, CMFP_ERR_INVALID, "Dirichlet face data of a mixture are not built");
     if (c->geom.is_periodic[dim]) return fail(c, CMFP_ERR_INVALID, "Dirichlet data on a periodic face");
     if ((cell_values == nullptr) != (face_values == nullptr)) return fail(c, CMFP_ERR_INVALID, "cell and face values go together");
     if (!cell_values) {

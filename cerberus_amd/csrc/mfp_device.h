@@ -300,6 +300,48 @@ CMFP_DEV void hydro_speed_from_prim(const GasP& G, const double* Q, double* s) {
     s[2] = a + fabs(Q[H_W]);
 }
 
+// Mixture of nt + 1 species (HydroParams::mix): the gas constants of a cell from its nt mass fractions, the last
+// species taking 1 - sum(alpha).  get_gamma_from_prim MFP_thermally_perfect_gas.cpp:51-83 (gamma_const returns
+// gamma[0]), get_mass_from_prim MFP_hydro_gas.cpp:50-70 (mass_const returns mass[0]); alpha clamped to [0, 1].
+CMFP_DEV double mix_clamp01(double a) { return (a < 0.0) ? 0.0 : ((1.0 < a) ? 1.0 : a); }
+CMFP_DEV GasP mix_gas(const cmfp::HydroParams& hp, const double* alpha) {
+    GasP G = hp.gas;
+    double a0 = 0.0, a1 = 0.0;
+    if (hp.nt > 0) a0 = mix_clamp01(alpha[0]);
+    if (hp.nt > 1) a1 = mix_clamp01(alpha[1]);
+    if (hp.mix & 1) {
+        double S_a = 0.0, S_cp = 0.0, S_cv = 0.0;
+        if (hp.nt > 0) {
+            S_a += a0;
+            S_cp += a0 * hp.sp_cp[0];
+            S_cv += a0 * hp.sp_cv[0];
+        }
+        if (hp.nt > 1) {
+            S_a += a1;
+            S_cp += a1 * hp.sp_cp[1];
+            S_cv += a1 * hp.sp_cv[1];
+        }
+        const double cpl = hp.nt > 1 ? hp.sp_cp[2] : hp.sp_cp[1], cvl = hp.nt > 1 ? hp.sp_cv[2] : hp.sp_cv[1];
+        S_cp += (1.0 - S_a) * cpl;
+        S_cv += (1.0 - S_a) * cvl;
+        G.gamma = f_div(S_cp, S_cv);
+    }
+    if (hp.mix & 2) {
+        double S_a = 0.0, S_m = 0.0;
+        if (hp.nt > 0) {
+            S_a += a0;
+            S_m += f_div(a0, hp.sp_mass[0]);
+        }
+        if (hp.nt > 1) {
+            S_a += a1;
+            S_m += f_div(a1, hp.sp_mass[1]);
+        }
+        S_m += f_div(1.0 - S_a, hp.nt > 1 ? hp.sp_mass[2] : hp.sp_mass[1]);
+        G.mass = f_div(1.0, S_m);
+    }
+    return G;
+}
+
 // ------------------------------------------------------------ Riemann: hydro
 // What the passive-scalar (tracer) fluxes need from a hydro Riemann solve: HLLC (MFP_hllc.cpp:100,
 // 111-137,147-173,183): side K the flux was taken from, its normal velocity and density, and in a
@@ -545,13 +587,14 @@ template <int FLUX> CMFP_DEV void hydro_riemann(const double* L, const double* R
 // hydro face flux incl. nt passive scalars: L, R carry alpha behind the five primitives, F the tracer
 // fluxes behind the five conserved fluxes (HLLC / HLLE; the hybrid solver leaves tracer fluxes
 // undefined in the reference, quirk Q5, and is refused with tracers)
-template <int FLUX> CMFP_DEV void hydro_riemann_tracers(const double* L, const double* R, double gam, int nt, double* F) {
+template <int FLUX>
+CMFP_DEV void hydro_riemann_tracers(const double* L, const double* R, double gamL, double gamR, int nt, double* F) {
     HllAux x;
     if (FLUX == 0) {
-        hllc_solve(L, R, gam, gam, F, &x);
+        hllc_solve(L, R, gamL, gamR, F, &x);
         for (int t = 0; t < nt; ++t) F[5 + t] = hllc_tracer_flux(x, L, R, L[5 + t], R[5 + t]);
     } else {
-        hlle_solve(L, R, gam, gam, F, &x);
+        hlle_solve(L, R, gamL, gamR, F, &x);
         for (int t = 0; t < nt; ++t) F[5 + t] = hlle_tracer_flux(x, L, R, L[5 + t], R[5 + t]);
     }
 }

@@ -57,7 +57,14 @@ __global__ void k_prim(Geo g, IBox box, HydroParams hp, const double* __restrict
         double u[5], q[5];
 #pragma unroll
         for (int n = 0; n < 5; ++n) u[n] = U[t + n * g.sc];
-        if (!hydro_cons2prim(hp.gas, u, q)) *err = 1;
+        GasP G = hp.gas;
+        if (hp.mix) {  // get_gamma_from_cons / get_mass_from_cons: alpha_i = tracer_i / rho
+            double al[2] = {0.0, 0.0};
+            for (int n = 0; n < hp.nt; ++n) al[n] = f_div(U[t + (5 + n) * g.sc], u[0]);
+            G = mix_gas(hp, al);
+            Q[t + (5 + hp.nt) * g.sc] = G.gamma;  // Q[Gamma], MFP_thermally_perfect_gas.cpp:210
+        }
+        if (!hydro_cons2prim(G, u, q)) *err = 1;
 #pragma unroll
         for (int n = 0; n < 5; ++n) Q[t + n * g.sc] = q[n];
         if (hp.nt) {  // alpha = tracer * rhoinv (MFP_thermally_perfect_gas.cpp:212-214)
@@ -93,26 +100,57 @@ __global__ void k_recon(Geo g, IBox box, HydroParams hp, FieldParams fp, const d
         // the reference stores eps = p/(gamma-1) in place during reconstruction and
         // restores p = eps*(gamma-1) afterwards (MFP_hydro.cpp:847-862,1025-1035):
         // the time-average step sees that round-tripped pressure
-        const double gm1 = hp.gas.gamma - 1.0;
+        GasP Gc = hp.gas;
+        if (hp.mix) {  // get_gamma_from_prim(Q): from the cell's alpha (:857, MFP_thermally_perfect_gas.cpp:323)
+            double al[2] = {0.0, 0.0};
+            for (int n = 0; n < hp.nt; ++n) al[n] = Q[c0 + (5 + n) * g.sc];
+            Gc = mix_gas(hp, al);
+        }
+        const double gm1 = Gc.gamma - 1.0;
         centre[H_P] = (centre[H_P] / gm1) * gm1;
-        hydro_speed_from_prim(hp.gas, centre, speed);
+        hydro_speed_from_prim(Gc, centre, speed);
     } else {
         speed[0] = speed[1] = speed[2] = fp.fastest;
     }
 
     for (int d = 0; d < g.dim; ++d) {
         double lo[NQ], hi[NQ];
+        double gam_lo = 0.0, gam_hi = 0.0;  // mixtures: gamma of the two face states (:997-998)
         if (HYDRO) {
-            const double gm1 = hp.gas.gamma - 1.0;
             double st[SL][5];
 #pragma unroll
             for (int s = 0; s < SL; ++s) {
                 const long c = c0 + (long)(s - off) * str[d];
 #pragma unroll
                 for (int n = 0; n < 5; ++n) st[s][n] = Q[c + n * g.sc];
+                double gm1 = hp.gas.gamma - 1.0;
+                if (hp.mix) {  // every cell of the stencil with its own gamma (:857-859)
+                    double al[2] = {0.0, 0.0};
+                    for (int n = 0; n < hp.nt; ++n) al[n] = Q[c + (5 + n) * g.sc];
+                    gm1 = mix_gas(hp, al).gamma - 1.0;
+                }
                 st[s][H_P] = st[s][H_P] / gm1;
             }
-            hydro_cell_faces<RECON>(hp.gas.gamma, st, lo, hi);
+            if (!hp.mix) {
+                hydro_cell_faces<RECON>(hp.gas.gamma, st, lo, hi);
+            } else {
+                // gamma = 2 leaves eps -+ phi_eps / 2 in the pressure slots ((2 - 1) x is exact); the faces' own
+                // gamma comes from their alpha (:982-1002)
+                hydro_cell_faces<RECON>(2.0, st, lo, hi);
+                double alo[2] = {0.0, 0.0}, ahi[2] = {0.0, 0.0};
+                for (int n = 0; n < hp.nt; ++n) {
+                    double sa[SL];
+#pragma unroll
+                    for (int s = 0; s < SL; ++s) sa[s] = Q[c0 + (long)(s - off) * str[d] + (5 + n) * g.sc];
+                    const double phi_alpha = recon_slope<RECON>(sa);
+                    alo[n] = sa[off] - 0.5 * phi_alpha;
+                    ahi[n] = sa[off] + 0.5 * phi_alpha;
+                }
+                gam_lo = mix_gas(hp, alo).gamma;
+                gam_hi = mix_gas(hp, ahi).gamma;
+                lo[H_P] = lo[H_P] * (gam_lo - 1.0);
+                hi[H_P] = hi[H_P] * (gam_hi - 1.0);
+            }
         } else {
 #pragma unroll
             for (int n = 0; n < 10; ++n) {
@@ -146,6 +184,12 @@ __global__ void k_recon(Geo g, IBox box, HydroParams hp, FieldParams fp, const d
                 if (do_ctu) trace_faces(speed[d], 0.5 * dt / g.dx[d], st[off], alo, ahi);
                 plo[c0 + n * g.sc] = alo;
                 phi[c0 + n * g.sc] = ahi;
+            }
+            if (hp.mix) {  // the Gamma entry of the face states, traced like every primitive (:1013-1014)
+                const int GI = 5 + hp.nt;
+                if (do_ctu) trace_faces(speed[d], 0.5 * dt / g.dx[d], Q[c0 + GI * g.sc], gam_lo, gam_hi);
+                plo[c0 + GI * g.sc] = gam_lo;
+                phi[c0 + GI * g.sc] = gam_hi;
             }
         }
     }
@@ -207,7 +251,12 @@ __global__ void k_fluxes(Geo g, IBox fbox, int d, HydroParams hp, FieldParams fp
             }
             rot_g2l(Lt, H_U, d);
             rot_g2l(Rt, H_U, d);
-            hydro_riemann_tracers<FLUX>(Lt, Rt, hp.gas.gamma, hp.nt, Ft);
+            double gamL = hp.gas.gamma, gamR = hp.gas.gamma;
+            if (hp.mix) {  // L[Gamma], R[Gamma] (MFP_hllc.cpp:38,56)
+                gamL = rhi[cm + (5 + hp.nt) * g.sc];
+                gamR = rlo[c + (5 + hp.nt) * g.sc];
+            }
+            hydro_riemann_tracers<FLUX>(Lt, Rt, gamL, gamR, hp.nt, Ft);
             rot_l2g(Ft, 1, d);
             for (int n = 0; n < 5 + hp.nt; ++n) flux[c + n * g.sc] = 0.0 + Ft[n];
         }
@@ -248,6 +297,12 @@ __global__ void k_correct(Geo g, IBox faces, int d1, HydroParams hp, double* __r
         La[t] = rhi[cm + (5 + t) * g.sc];
         Ra[t] = rlo[c + (5 + t) * g.sc];
     }
+    const bool mix = HYDRO && hp.mix;
+    double Lg = 0.0, Rg = 0.0;  // mixtures: the Gamma entry of the two face states
+    if (mix) {
+        Lg = rhi[cm + (5 + nt) * g.sc];
+        Rg = rlo[c + (5 + nt) * g.sc];
+    }
     for (int dd = 1; dd < g.dim; ++dd) {
         const int d2 = (d1 + dd) % g.dim;
         const double* __restrict__ f = flux.p[d2];
@@ -262,8 +317,13 @@ __global__ void k_correct(Geo g, IBox faces, int d1, HydroParams hp, double* __r
             Rt[t] += 0.5 * dt / g.dx[d2] * (f[c + n * g.sc] - f[c + str[d2] + n * g.sc]);
         }
         if (HYDRO) {
-            hydro_prim2cons(hp.gas, Lp, Lc);
-            hydro_prim2cons(hp.gas, Rp, Rc);
+            GasP GL = hp.gas, GR = hp.gas;
+            if (hp.mix) {  // get_gamma_from_prim(Q): the face state's alpha
+                GL = mix_gas(hp, La);
+                GR = mix_gas(hp, Ra);
+            }
+            hydro_prim2cons(GL, Lp, Lc);
+            hydro_prim2cons(GR, Rp, Rc);
         } else {
 #pragma unroll
             for (int n = 0; n < 10; ++n) {
@@ -284,8 +344,20 @@ __global__ void k_correct(Geo g, IBox faces, int d1, HydroParams hp, double* __r
             Rc[n] += 0.5 * dt / g.dx[d2] * (loF - hiF);
         }
         if (HYDRO) {
-            if (!hydro_cons2prim(hp.gas, Lc, Lp)) *err = 1;
-            if (!hydro_cons2prim(hp.gas, Rc, Rp)) *err = 1;
+            GasP GL = hp.gas, GR = hp.gas;
+            if (hp.mix) {  // get_gamma_from_cons / get_mass_from_cons of the corrected state
+                double al[2] = {0.0, 0.0}, ar[2] = {0.0, 0.0};
+                for (int t = 0; t < nt; ++t) {
+                    al[t] = f_div(Lt[t], Lc[0]);
+                    ar[t] = f_div(Rt[t], Rc[0]);
+                }
+                GL = mix_gas(hp, al);
+                GR = mix_gas(hp, ar);
+                Lg = GL.gamma;
+                Rg = GR.gamma;
+            }
+            if (!hydro_cons2prim(GL, Lc, Lp)) *err = 1;
+            if (!hydro_cons2prim(GR, Rc, Rp)) *err = 1;
             if (nt) {
                 const double rinvL = f_rcp(Lc[0]), rinvR = f_rcp(Rc[0]);
                 for (int t = 0; t < nt; ++t) {
@@ -309,6 +381,10 @@ __global__ void k_correct(Geo g, IBox faces, int d1, HydroParams hp, double* __r
     for (int t = 0; t < nt; ++t) {
         rhi[cm + (5 + t) * g.sc] = La[t];
         rlo[c + (5 + t) * g.sc] = Ra[t];
+    }
+    if (mix) {
+        rhi[cm + (5 + nt) * g.sc] = Lg;
+        rlo[c + (5 + nt) * g.sc] = Rg;
     }
 }
 
@@ -665,8 +741,14 @@ __global__ void k_first_invalid(Geo g, IBox box, HydroParams hp, const double* _
     double u[5], q[5];
 #pragma unroll
     for (int n = 0; n < 5; ++n) u[n] = U[t + n * g.sc];
-    const double T = (u[4] - 0.5 * (u[1] * u[1] + u[2] * u[2] + u[3] * u[3]) / u[0]) * (hp.gas.gamma - 1) / u[0] * hp.gas.mass;
-    if (!hydro_cons2prim(hp.gas, u, q) || !(T > 0.0))  // NaNs count as invalid here
+    GasP G = hp.gas;
+    if (hp.mix) {
+        double al[2] = {0.0, 0.0};
+        for (int n = 0; n < hp.nt; ++n) al[n] = f_div(U[t + (5 + n) * g.sc], u[0]);
+        G = mix_gas(hp, al);
+    }
+    const double T = (u[4] - 0.5 * (u[1] * u[1] + u[2] * u[2] + u[3] * u[3]) / u[0]) * (G.gamma - 1) / u[0] * G.mass;
+    if (!hydro_cons2prim(G, u, q) || !(T > 0.0))  // NaNs count as invalid here
         atomicMin(out, (unsigned long long)(((long)k * g.n[1] + j) * g.n[0] + i));
 }
 static void l_first_invalid(const Geo& g, const StatePhys& sp, const double* U, unsigned long long* out, hipStream_t st) {
@@ -933,7 +1015,13 @@ __global__ void k_max_speed(Geo g, IBox box, HydroParams hp, const double* __res
         double u[5];
 #pragma unroll
         for (int n = 0; n < 5; ++n) u[n] = U[c + n * g.sc];
-        m = cell_max_speed(hp.gas, u, g.dim, m);
+        GasP G = hp.gas;
+        if (hp.mix) {  // get_gamma_from_cons (MFP_thermally_perfect_gas.cpp:309)
+            double al[2] = {0.0, 0.0};
+            for (int n = 0; n < hp.nt; ++n) al[n] = f_div(U[c + (5 + n) * g.sc], u[0]);
+            G = mix_gas(hp, al);
+        }
+        m = cell_max_speed(G, u, g.dim, m);
     }
     block_reduce_store<true>(m, part);
 }
@@ -1145,6 +1233,8 @@ static FillRules face_rules(const StatePhys& sp, int d, int side) {
         // never reach the conserved result with a single-species gas; alpha (primitive 8+) keeps its
         // reconstructed face value.  The carried slots 5+ are alpha: skip them.
         if (sp.kind == 0 && n >= 5) bc = -666;
+        // mixtures carry Gamma (primitive 6) in slot 5 + nt: with two tracers it takes fill_bc[6], else bogus
+        if (sp.kind == 0 && sp.hp.mix && n == 5 + sp.hp.nt && sp.hp.nt == 2) bc = sp.bc[6][d][side];
         r.rule[n] = (bc == 2 || bc == 4 || bc == 1) ? FILL_EVEN : (bc == -1 ? FILL_ODD : FILL_SKIP);
     }
     return r;

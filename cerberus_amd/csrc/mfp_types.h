@@ -11,6 +11,11 @@ struct HydroParams {
     GasP gas;
     double shock_threshold;
     int nt;  // passive scalars (n_tracers): comps 5 .. 5 + nt - 1 of the conserved / primitive / flux arrays
+    // true mixture (cmfp_state_desc::mixture): bit 0 = gamma differs between the species, bit 1 = mass differs.
+    // Per species cp = gamma / (mass (gamma - 1)), cv = 1 / (mass (gamma - 1)) and mass; the stage-by-stage kernels
+    // then carry gamma as primitive 5 + nt (the reference's Gamma entry of the face states).
+    int mix;
+    double sp_cp[3], sp_cv[3], sp_mass[3];
 };
 struct FieldParams {
     double c0;       // MFP::lightspeed

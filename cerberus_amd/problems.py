@@ -96,6 +96,65 @@ def with_tracers(cfg, state, alphas):
     return cfg
 
 
+def with_mixture(cfg, state, alphas, masses, gammas):
+    """Makes hydro state `state` a mixture of len(alphas) + 1 species of the given masses and gammas
+    (ThermallyPerfectGas with mass_const / gamma_const false, MFP_thermally_perfect_gas.cpp:32-34):
+    value.alpha = mass fractions of all species but the last."""
+    sd = cfg["states"][state]
+    n = len(alphas) + 1
+    if len(masses) != n or len(gammas) != n:
+        raise ValueError("one mass and one gamma per species")
+    gas = sd["gas"]
+    q = gas["charge"]
+    gas["mass"], gas["gamma"] = [float(m) for m in masses], [float(g) for g in gammas]
+    gas["charge"] = [q[0] if isinstance(q, (list, tuple)) else q] * n
+    sd["value"]["alpha"] = list(alphas)
+    return cfg
+
+
+def shock_bubble_2d(nx=64, ny=32, dim=2, nz=8, recon="vanLeer", flux="HLLC", species=2):
+    """A Mach-1.5 shock in air (gamma 1.4) running over a helium-like bubble (gamma 5/3, mass 0.138): the classic
+    two-gas test of a mixture gas model.  Walls in y, outflow in x; `species` = 3 adds a heavy third gas in a band."""
+    gam = 1.4
+    M = 1.5
+    p1, r1 = 1.0, 1.0
+    p2 = p1 * (1 + 2 * gam / (gam + 1) * (M * M - 1))
+    r2 = r1 * ((gam + 1) * M * M) / ((gam - 1) * M * M + 2)
+    a1 = math.sqrt(gam * p1 / r1)
+    u2 = M * a1 * (1 - r1 / r2)
+    post = lambda d: d["x"] < 0.2
+    R = lambda d: np.sqrt((d["x"] - 0.45) ** 2 + (d["y"] - 0.25) ** 2 + ((d["z"] - 0.0625) ** 2 if dim == 3 else 0.0))
+    # smooth bubble edge: mass fraction of air
+    air = lambda d: 0.5 * (1 + np.tanh((R(d) - 0.15) / 0.03))
+    rho = lambda d: np.where(post(d), r2, r1 * (air(d) + (1 - air(d)) * 0.138))
+    alphas = [air]
+    masses, gammas = [1.0, 0.138], [gam, 5.0 / 3.0]
+    if species == 3:
+        band = lambda d: 0.3 * (np.abs(d["x"] - 0.75) < 0.08)
+        alphas = [lambda d: air(d) - band(d), band]
+        masses, gammas = [1.0, 2.0, 0.138], [gam, 1.1, 5.0 / 3.0]
+    wall = {"lo": {"fill_hydro_bc": "slipwall"}, "hi": {"fill_hydro_bc": "slipwall"}}
+    out = {"lo": {"fill_hydro_bc": "outflow"}, "hi": {"fill_hydro_bc": "outflow"}}
+    cfg = {
+        "dim": dim, "n_cell": [nx, ny, nz][:dim], "prob_lo": [0.0] * dim, "prob_hi": [1.0, 0.5, 0.125][:dim],
+        "is_periodic": [0, 0, 1][:dim], "cfl": 0.4, "time_integration_scheme": "strang", "lightspeed": 1.0,
+        "states": {
+            "fluid": {
+                "type": "hydro",
+                "gas": {"type": "thermally_perfect", "mass": 1.0, "charge": 0.0, "gamma": gam},
+                "reconstruction": recon, "flux": flux,
+                "value": {"rho": rho, "x_vel": lambda d: np.where(post(d), u2, 0.0), "y_vel": 0.0, "z_vel": 0.0,
+                          "p": lambda d: np.where(post(d), p2, p1)},
+                "bc": {"x": out, "y": wall},
+            },
+        },
+        "actions": {"fluxes": {"type": "CTU", "corner_transport": True, "states": ["fluid"]}},
+    }
+    if dim == 1:
+        del cfg["states"]["fluid"]["bc"]["y"]
+    return with_mixture(cfg, "fluid", alphas, masses, gammas)
+
+
 def orszag_tang_two_fluid_2d(n=4096, solver="explicit", source="plasma5", collisions=False):
     gam = 5 / 3
     c = 20.0

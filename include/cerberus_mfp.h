@@ -142,13 +142,24 @@ typedef struct {
      * mu0 / (rho_ref x_ref u_ref), T0 / T_ref, S / T_ref.  2-D and 1-D blocks only. */
     int viscosity;          /* cmfp_viscosity */
     double visc_mu0, visc_T0, visc_S, visc_n, visc_Pr;
-    /* hydro: passive scalars `alpha` of a single-species gas (value.alpha = {...},
+    /* hydro: mass fractions `alpha` of a gas of n_tracers + 1 species (value.alpha = {...}; passive scalars where
+     * the species have equal mass and gamma, see `mixture` below;
      * HydroState::n_tracers MFP_hydro.cpp:296-323): conserved comps 5 .. 5 + n_tracers - 1 hold
      * rho * alpha (MFP_thermally_perfect_gas.cpp:212-214,243-245).  0 <= n_tracers <= 2. */
     int n_tracers;
     /* BCRec per conserved component: bc[comp][dim][0=lo,1=hi] (cmfp_bc).
      * hydro uses comps 0..4 (+ n_tracers), field 0..9. */
     int bc[CMFP_MAX_COMP][CMFP_MAX_DIM][2];
+    /* hydro: a gas of n_tracers + 1 species of different mass / gamma (ThermallyPerfectGas::get_gamma_from_prim /
+     * _from_cons, get_cp_*, MFP_thermally_perfect_gas.cpp:51-177; HydroGas::get_mass_from_*, MFP_hydro_gas.cpp:50-96):
+     * mixture != 0 reads species_mass / species_gamma [0 .. n_tracers] (mass, gamma above = species 0) and gamma,
+     * mass of a cell follow its mass fractions alpha_i = tracer_i / rho, the last species taking 1 - sum(alpha).
+     * Built for the transport of the state (CTU / RK2 / euler updates and its dt limit, stage-by-stage kernels):
+     * a mixture state in a source action, with viscosity or with Dirichlet face data is refused by cmfp_create /
+     * cmfp_set_face_values (species charges, which only sources read, are not carried). */
+    int mixture;
+    double species_mass[CMFP_MAX_TRACERS + 1];
+    double species_gamma[CMFP_MAX_TRACERS + 1];
 } cmfp_state_desc;
 
 /* One action, in sorted-name order (MFP_config.cpp:261-291). */

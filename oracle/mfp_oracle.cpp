@@ -19,7 +19,7 @@
 // (AMReX fab_filcc, source absent) and the time integrator glue have no
 // reference fixture: for those, PARITY IS UNPINNED by the reference.
 //
-// Restrictions (round 1): single-species hydro states (n_tracers = 0), no EB,
+// Restrictions: mixtures (species of different mass / gamma) in the transport only, no EB,
 // no Lua inflow / dynamic functions, no viscous terms, single AMR level.
 
 #include "../include/cerberus_mfp.h"
@@ -222,13 +222,64 @@ static void recon_face_values(int r, const Real* stencil, Real& lo, Real& hi) {
 }
 
 // ---------------------------------------------------------------------------
-// Gas model — hydro/gas/MFP_thermally_perfect_gas.cpp (single species: the
-// mass_const / gamma_const short-circuits :55,91,127,155 and
-// MFP_hydro_gas.cpp:54,78,102,129 always apply)
+// Gas model — hydro/gas/MFP_thermally_perfect_gas.cpp, MFP_hydro_gas.cpp.  A gas of nt + 1 species carries
+// nt mass fractions alpha; where every species has the same mass / gamma the mass_const / gamma_const
+// short-circuits (:55,91,127,155, MFP_hydro_gas.cpp:54,78) return the constants of species 0.
+static inline Real clamp01(Real a) { return (a < 0.0) ? 0.0 : ((1.0 < a) ? 1.0 : a); }  // std::clamp(a, 0.0, 1.0)
 struct Gas {
-    Real mass, charge, gamma;
-    int nt = 0;  // n_tracers: passive scalars alpha (mass, charge, gamma stay the constants of species 0)
+    Real mass, charge, gamma;  // species 0
+    int nt = 0;                // n_tracers = n_species - 1
+    bool mass_const = true, gamma_const = true;
+    Real sm[CMFP_MAX_TRACERS + 1] = {0}, sg[CMFP_MAX_TRACERS + 1] = {0};  // per-species mass, gamma
     Real cp() const { return gamma / (mass * (gamma - 1)); }  // :127
+    // get_gamma_from_prim :51-83 (alpha: the nt mass fractions)
+    Real gamma_from_alpha(const Real* alpha) const {
+        if (gamma_const) return gamma;
+        Real S_alphaicpi = 0.0, S_alphaicvi = 0.0, S_alphai = 0.0, cvi, cpi, alphai;
+        for (int i = 0; i < nt; ++i) {
+            alphai = clamp01(alpha[i]);
+            S_alphai += alphai;
+            cpi = sg[i] / (sm[i] * (sg[i] - 1.0));
+            cvi = 1.0 / (sm[i] * (sg[i] - 1.0));
+            S_alphaicpi += alphai * cpi;
+            S_alphaicvi += alphai * cvi;
+        }
+        cpi = sg[nt] / (sm[nt] * (sg[nt] - 1.0));
+        cvi = 1.0 / (sm[nt] * (sg[nt] - 1.0));
+        S_alphaicpi += (1.0 - S_alphai) * cpi;
+        S_alphaicvi += (1.0 - S_alphai) * cvi;
+        return S_alphaicpi / S_alphaicvi;
+    }
+    // get_cp_from_prim :123-147
+    Real cp_from_alpha(const Real* alpha) const {
+        if (gamma_const && mass_const) return cp();
+        Real S_alphai = 0.0, S_alphaicpi = 0.0, cpi, alphai;
+        for (int i = 0; i < nt; ++i) {
+            alphai = clamp01(alpha[i]);
+            S_alphai += alphai;
+            cpi = sg[i] / (sm[i] * (sg[i] - 1.0));
+            S_alphaicpi += alphai * cpi;
+        }
+        cpi = sg[nt] / (sm[nt] * (sg[nt] - 1.0));
+        S_alphaicpi += (1.0 - S_alphai) * cpi;
+        return S_alphaicpi;
+    }
+    // HydroGas::get_mass_from_prim MFP_hydro_gas.cpp:50-70
+    Real mass_from_alpha(const Real* alpha) const {
+        if (mass_const) return mass;
+        Real S_alphai_mi = 0.0, S_alphas = 0.0, alphai;
+        for (int i = 0; i < nt; ++i) {
+            alphai = clamp01(alpha[i]);
+            S_alphas += alphai;
+            S_alphai_mi += alphai / sm[i];
+        }
+        S_alphai_mi += (1.0 - S_alphas) / sm[nt];
+        return 1.0 / S_alphai_mi;
+    }
+    // the *_from_cons forms (:85-121,149-177, MFP_hydro_gas.cpp:72-96): alpha_i = U[tracer_i] / rho
+    void alpha_from_cons(const Real* U, Real* alpha) const {
+        for (int i = 0; i < nt; ++i) alpha[i] = U[5 + i] / U[0];
+    }
 };
 
 // HydroGas::prim_valid  MFP_hydro_gas.cpp:152-164
@@ -253,9 +304,11 @@ static bool gas_cons2prim(const Gas& G, const Real* U, Real* Q) {
     Real v = my * rhoinv;
     Real w = mz * rhoinv;
     Real ke = 0.5 * rho * (u * u + v * v + w * w);
-    Real m = G.mass;
-    Real g = G.gamma;
-    Real cp = G.cp();
+    Real alpha[CMFP_MAX_TRACERS + 1];
+    G.alpha_from_cons(U, alpha);
+    Real m = G.mass_from_alpha(alpha);    // get_mass_from_cons
+    Real g = G.gamma_from_alpha(alpha);   // get_gamma_from_cons
+    Real cp = G.cp_from_alpha(alpha);     // get_cp_from_cons
     Real p = (ed - ke) * (g - 1);
     Real T = p * rhoinv * m;
 
@@ -283,7 +336,7 @@ static void gas_prim2cons(const Gas& G, const Real* Q, Real* U) {
     Real my = v * rho;
     Real mz = w * rho;
     Real ke = 0.5 * rho * (u * u + v * v + w * w);
-    Real g = G.gamma;
+    Real g = G.gamma_from_alpha(Q + HP_NUM);  // get_gamma_from_prim(Q)
     Real ed = p / (g - 1) + ke;
 
     U[Density] = rho;
@@ -308,7 +361,9 @@ static void gas_speed_from_cons(const Gas& G, const Real* U, Real* s) {
     Real v = my * rhoinv;
     Real w = mz * rhoinv;
     Real ke = 0.5 * rho * (u * u + v * v + w * w);
-    Real g = G.gamma;
+    Real alpha[CMFP_MAX_TRACERS + 1];
+    G.alpha_from_cons(U, alpha);
+    Real g = G.gamma_from_alpha(alpha);  // get_gamma_from_cons
     Real p = (ed - ke) * (g - 1);
     Real a = std::sqrt(g * p * rhoinv);
     s[0] = a + std::abs(u);
@@ -318,7 +373,7 @@ static void gas_speed_from_cons(const Gas& G, const Real* U, Real* s) {
 
 // ThermallyPerfectGas::get_speed_from_prim :319-332
 static void gas_speed_from_prim(const Gas& G, const Real* Q, Real* s) {
-    Real g = G.gamma;
+    Real g = G.gamma_from_alpha(Q + HP_NUM);  // get_gamma_from_prim(Q)
     Real a = std::sqrt(g * Q[Prs] / Q[PDensity]);
     s[0] = a + std::abs(Q[Xvel]);
     s[1] = a + std::abs(Q[Yvel]);
@@ -926,6 +981,7 @@ static void calc_reconstruction_hydro(const StateDef& S, int DIM, const Box& box
     int si[3];
     Real Q[CMFP_MAX_COMP], cell_slope[CMFP_MAX_COMP];
     Real rho_lo, rho_hi, abs_phi, phi_scale, coeff_eps, gam_lo, gam_hi;
+    Real alphas_lo[CMFP_MAX_TRACERS + 1], alphas_hi[CMFP_MAX_TRACERS + 1];
 
     for (int d = 0; d < DIM; ++d) {
         rlo[d].resize(box, S.n_prim);
@@ -936,7 +992,9 @@ static void calc_reconstruction_hydro(const StateDef& S, int DIM, const Box& box
     for (int k = pbox.lo[2]; k <= pbox.hi[2]; ++k)
         for (int j = pbox.lo[1]; j <= pbox.hi[1]; ++j)
             for (int i = pbox.lo[0]; i <= pbox.hi[0]; ++i) {
-                gamma_minus_one(i, j, k, 0) = S.gas.gamma - 1.0;
+                Real al[CMFP_MAX_TRACERS + 1];
+                for (int n = 0; n < S.gas.nt; ++n) al[n] = prim(i, j, k, HP_NUM + n);
+                gamma_minus_one(i, j, k, 0) = S.gas.gamma_from_alpha(al) - 1.0;  // get_gamma_from_prim(Q) :857
                 prim(i, j, k, Prs) /= gamma_minus_one(i, j, k, 0);
             }
 
@@ -1014,22 +1072,24 @@ static void calc_reconstruction_hydro(const StateDef& S, int DIM, const Box& box
                         Real alpha_hi = alpha + 0.5 * phi_alpha;
                         lo4(i, j, k, HP_NUM + n) = alpha_lo;
                         hi4(i, j, k, HP_NUM + n) = alpha_hi;
+                        alphas_lo[n] = alpha_lo;
+                        alphas_hi[n] = alpha_hi;
                     }
 
-                    gam_lo = S.gas.gamma;  // get_gamma_from_prim(alphas_lo, 0), gamma_const
-                    gam_hi = S.gas.gamma;
+                    gam_lo = S.gas.gamma_from_alpha(alphas_lo);  // get_gamma_from_prim(alphas_lo, 0) :997
+                    gam_hi = S.gas.gamma_from_alpha(alphas_hi);
 
                     lo4(i, j, k, Prs) = (eps - 0.5 * phi_eps) * (gam_lo - 1.0);
                     hi4(i, j, k, Prs) = (eps + 0.5 * phi_eps) * (gam_hi - 1.0);
 
-                    lo4(i, j, k, Temp) = lo4(i, j, k, Prs) / (rho_lo / S.gas.mass);
-                    hi4(i, j, k, Temp) = hi4(i, j, k, Prs) / (rho_hi / S.gas.mass);
+                    lo4(i, j, k, Temp) = lo4(i, j, k, Prs) / (rho_lo / S.gas.mass_from_alpha(alphas_lo));
+                    hi4(i, j, k, Temp) = hi4(i, j, k, Prs) / (rho_hi / S.gas.mass_from_alpha(alphas_hi));
 
                     lo4(i, j, k, Gamma) = gam_lo;
                     hi4(i, j, k, Gamma) = gam_hi;
 
-                    lo4(i, j, k, SpHeat) = S.gas.cp();
-                    hi4(i, j, k, SpHeat) = S.gas.cp();
+                    lo4(i, j, k, SpHeat) = S.gas.cp_from_alpha(alphas_lo);
+                    hi4(i, j, k, SpHeat) = S.gas.cp_from_alpha(alphas_hi);
                 }
     }
 
@@ -2045,6 +2105,12 @@ static void setup_state(StateDef& S, const cmfp_state_desc& d, const cmfp_params
     if (d.kind == CMFP_STATE_HYDRO && d.viscosity) S.num_grow = std::max(S.num_grow, 2);  // MFP_hydro.cpp:108-110
     if (d.kind == CMFP_STATE_HYDRO) {
         S.gas = Gas{d.mass, d.charge, d.gamma, d.n_tracers};
+        for (int i = 0; i <= d.n_tracers; ++i) {  // mass_const / gamma_const MFP_thermally_perfect_gas.cpp:32-34
+            S.gas.sm[i] = d.mixture ? d.species_mass[i] : d.mass;
+            S.gas.sg[i] = d.mixture ? d.species_gamma[i] : d.gamma;
+            if (S.gas.sm[i] != S.gas.sm[0]) S.gas.mass_const = false;
+            if (S.gas.sg[i] != S.gas.sg[0]) S.gas.gamma_const = false;
+        }
         S.n_cons = HC_NUM + d.n_tracers;  // MFP_hydro.H n_cons() / n_prim()
         S.n_prim = HP_NUM + d.n_tracers;
         S.vec_prim[0] = Xvel;  // MFP_hydro.cpp:32-33
@@ -2168,6 +2234,14 @@ void* orc_create(const cmfp_geometry* g, const cmfp_params* p, int n_states, con
     for (int s = 0; s < n_states; ++s) setup_state(S->states[s], sd[s], *p);
     S->actions.resize(n_actions);
     for (int a = 0; a < n_actions; ++a) S->actions[a].desc = ad[a];
+    // mixtures are restated for the transport only: the sources, the viscous fluxes and the Dirichlet tables
+    // below keep the constants of species 0
+    for (int s = 0; s < n_states; ++s)
+        if (sd[s].kind == CMFP_STATE_HYDRO && sd[s].mixture && sd[s].viscosity) flag_abort();
+    for (int a = 0; a < n_actions; ++a)
+        if (ad[a].kind != CMFP_ACTION_CTU)
+            for (int n = 0; n < ad[a].n_states; ++n)
+                if (sd[ad[a].states[n]].kind == CMFP_STATE_HYDRO && sd[ad[a].states[n]].mixture) flag_abort();
     // chop the domain into boxes of at most max_grid cells per side
     int nb[3], bs[3];
     for (int d = 0; d < 3; ++d) {
@@ -2205,6 +2279,7 @@ void orc_destroy(void* h) { delete (Sim*)h; }
 void orc_set_face_values(void* h, int s, int d, int side, int prim, int tng, const double* cell, const double* face) {
     Sim* S = (Sim*)h;
     StateDef& st = S->states[s];
+    if (st.desc.mixture) flag_abort();
     st.tng = tng;
     const Box cb = tab_box(S->G.domain, S->G.DIM, tng, d, side, false), fb = tab_box(S->G.domain, S->G.DIM, tng, d, side, true);
     st.tab[d][side][prim].cell.assign(cell, cell + cb.npts());
