@@ -76,6 +76,7 @@ class StateDesc(C.Structure):
         ("mixture", C.c_int),
         ("species_mass", C.c_double * (MAX_TRACERS + 1)),
         ("species_gamma", C.c_double * (MAX_TRACERS + 1)),
+        ("species_charge", C.c_double * (MAX_TRACERS + 1)),
     ]
 
 

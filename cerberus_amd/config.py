@@ -74,20 +74,16 @@ def gas_list(gas, key):
 
 
 def gas_is_mixture(gas):
-    """True where the species differ in mass or gamma (mass_const / gamma_const false,
-    MFP_thermally_perfect_gas.cpp:32-34): gamma, mass and cp of a cell then follow its mass fractions."""
-    return any(x != v[0] for v in (gas_list(gas, "mass"), gas_list(gas, "gamma")) for x in v)
+    """True where the species differ in mass, charge or gamma (mass_const / charge_const / gamma_const false,
+    MFP_thermally_perfect_gas.cpp:32-34): gamma, mass, charge and cp of a cell then follow its mass fractions."""
+    return any(x != v[0] for v in (gas_list(gas, "mass"), gas_list(gas, "gamma"), gas_list(gas, "charge")) for x in v)
 
 
 def gas_scalar(gas, key):
     """mass / charge / gamma of species 0: the constants of the gas where every species has the same
     (mass_const, charge_const, gamma_const, MFP_thermally_perfect_gas.cpp:33-35: the tracers are then
-    passive scalars).  Species of different charge are read by the sources only, which are not built
-    for mixtures."""
-    v = gas_list(gas, key)
-    if key == "charge" and any(x != v[0] for x in v):
-        raise NotImplementedError("species of different charge (sources of a mixture) are not built")
-    return v[0]
+    passive scalars)."""
+    return gas_list(gas, key)[0]
 
 
 def gas_gamma_from_alpha(gas, alpha):
@@ -192,6 +188,8 @@ class Problem:
                         d.species_mass[k] = x
                     for k, x in enumerate(gas_list(gas, "gamma")):
                         d.species_gamma[k] = x
+                    for k, x in enumerate(gas_list(gas, "charge")):
+                        d.species_charge[k] = x
                     if sd.get("viscosity"):
                         raise NotImplementedError("viscous fluxes of a mixture are not built")
                 d.flux = abi.FLUX[sd["flux"]]
@@ -275,7 +273,7 @@ class Problem:
                         a.cross_sections[ib][ia] = s
                 if not ad.get("cross_sections"):
                     for n in names:
-                        if float(self.cfg["states"][n]["gas"]["charge"]) == 0.0:
+                        if gas_scalar(self.cfg["states"][n]["gas"], "charge") == 0.0:
                             raise ValueError(f"cross sections for collisions involving neutral species '{n}' are "
                                              f"required by action '{name}'")
             a.n_states = len(idx)

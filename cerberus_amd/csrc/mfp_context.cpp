@@ -294,6 +294,16 @@ SourceArgs source_args(cmfp_context* c, const cmfp_action_desc& A, bool on_new) 
         a.sp_U[n] = on_new ? s.new_data : s.U;
         a.sp_dU[n] = s.dU;
         a.r[n] = s.desc.charge / s.desc.mass;  // r = q / m  (MFP_plasma5.cpp:199-202)
+        if (s.desc.mixture) {  // get_mass_from_cons / get_charge_from_cons per cell
+            SpeciesMix& M = a.mix[n];
+            for (int i = 0; i <= s.desc.n_tracers; ++i) {
+                M.m[i] = s.desc.species_mass[i];
+                M.q[i] = s.desc.species_charge[i];
+                if (M.m[i] != M.m[0]) M.flags |= 1;
+                if (M.q[i] != M.q[0]) M.flags |= 2;
+            }
+            M.nt = M.flags ? s.desc.n_tracers : 0;
+        }
     }
     StateRT& f = c->states[A.states[A.n_states - 1]];
     a.f_U = on_new ? f.new_data : f.U;
@@ -1268,8 +1278,9 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
                     if (gm != states[s].species_gamma[0]) sp.hp.mix |= 1;
                     if (m != states[s].species_mass[0]) sp.hp.mix |= 2;
                 }
-                if (states[s].species_mass[0] != states[s].mass || states[s].species_gamma[0] != states[s].gamma)
-                    return fail(c, CMFP_ERR_INVALID, "mixture: mass / gamma must be those of species 0");
+                if (states[s].species_mass[0] != states[s].mass || states[s].species_gamma[0] != states[s].gamma ||
+                    states[s].species_charge[0] != states[s].charge)
+                    return fail(c, CMFP_ERR_INVALID, "mixture: mass / charge / gamma must be those of species 0");
                 if (sp.hp.mix) sp.nq = sp.nc + 1;  // the face states' Gamma entry travels with the primitives
             }
         } else if (sp.kind == CMFP_STATE_FIELD) {
@@ -1292,10 +1303,10 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
         for (int i = 0; i < A.n_states; ++i)
             if (A.states[i] < 0 || A.states[i] >= n_states) return fail(c, CMFP_ERR_INVALID, "bad action state index");
         if (A.kind == CMFP_ACTION_CTU) continue;
-        for (int i = 0; i < A.n_states; ++i)
-            if (c->states[A.states[i]].sp.kind == CMFP_STATE_HYDRO && c->states[A.states[i]].sp.hp.mix)
-                return fail(c, CMFP_ERR_INVALID, "source actions on a mixture (per-cell mass / charge) are not built");
         if (A.kind == CMFP_ACTION_COLLISIONS_RAMBO) {
+            for (int i = 0; i < A.n_states; ++i)
+                if (c->states[A.states[i]].desc.mixture)
+                    return fail(c, CMFP_ERR_INVALID, "collisions_rambo on a mixture (per-cell mass / charge) is not built");
             if (A.n_states > 4) return fail(c, CMFP_ERR_INVALID, "at most 4 species per collisions action");
             for (int i = 0; i < A.n_states; ++i)
                 if (c->states[A.states[i]].sp.kind != CMFP_STATE_HYDRO)  // MFP_collisions.cpp:35
@@ -1795,6 +1806,8 @@ int cmfp_elliptic_project(cmfp_context* c, int fs, int n_species, const int* spe
     for (int n = 0; n < n_species; ++n) {
         if (species[n] < 0 || species[n] >= (int)c->states.size() || c->states[species[n]].sp.kind != CMFP_STATE_HYDRO)
             return fail(c, CMFP_ERR_INVALID, "elliptic: species must be hydro states");
+        if (c->states[species[n]].desc.mixture)
+            return fail(c, CMFP_ERR_INVALID, "elliptic: the charge density of a mixture (per-cell charge / mass) is not built");
         q.rho[n] = c->states[species[n]].new_data;                                  // Density component
         q.r[n] = c->states[species[n]].desc.charge / c->states[species[n]].desc.mass;
     }

@@ -562,7 +562,7 @@ __global__ void k_collisions(Geo g, IBox box, SourceArgs a, double dt) {
 // Schur system for E.  Same solution to rounding (tested to 1e-12).
 template <int MAXS>
 CMFP_DEV void plasma5_implicit_cell(const SourceArgs& a, const SourceCoef& kf, double dt, const double* fU,
-                                    const double (*sU)[5], double (*sdU)[4], double* fdU) {
+                                    const double (*sU)[5], double (*sdU)[4], double* fdU, const double* rc = nullptr) {
     const double Larmor = a.Larmor, Debye = a.Debye, lightspeed = a.lightspeed;
     const double ep = fU[F_EP];
     const double B[3] = {fU[F_BX], fU[F_BY], fU[F_BZ]};
@@ -576,7 +576,7 @@ CMFP_DEV void plasma5_implicit_cell(const SourceArgs& a, const SourceCoef& kf, d
     for (int n = 0; n < MAXS; ++n) {
         if (n < a.n_species) {
             const double rho = sU[n][0];
-            const double r = a.r[n];
+            const double r = rc ? rc[n] : a.r[n];
             charge_density += rho * r;
             charge_density += rho * r;  // MFP_plasma5.cpp:370-372 counts it twice (quirk Q3)
             const double trace_B = -dt * r * rho * lightspeed / Larmor;
@@ -631,7 +631,7 @@ CMFP_DEV void plasma5_implicit_cell(const SourceArgs& a, const SourceCoef& kf, d
             sdU[n][0] = m[0] - m0[0];
             sdU[n][1] = m[1] - m0[1];
             sdU[n][2] = m[2] - m0[2];
-            sdU[n][3] = dt * (a.r[n] * lightspeed / Larmor) * (E[0] * m[0] + E[1] * m[1] + E[2] * m[2]);
+            sdU[n][3] = dt * ((rc ? rc[n] : a.r[n]) * lightspeed / Larmor) * (E[0] * m[0] + E[1] * m[1] + E[2] * m[2]);
         }
     }
     fdU[3] = -fU[F_PHI] * kf.f3 + kf.f2 * charge_density;
@@ -652,10 +652,13 @@ __global__ void k_source(Geo g, IBox box, SourceArgs a, SourceCoef kf, double dt
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int n = 0; n < 5; ++n) sU[s][n] = a.sp_U[s][c + n * g.sc];
+    double rc[NS];  // q / m of the cell's species (mixtures: from the mass fractions)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) rc[s] = species_r(g, a, s, c, sU[s][0]);
     if (IMPL)
-        plasma5_implicit_cell<NS>(a, kf, dt, fU, sU, sdU, fdU);
+        plasma5_implicit_cell<NS>(a, kf, dt, fU, sU, sdU, fdU, rc);
     else
-        plasma5_explicit_cell<NS>(a, kf, dt, fU, sU, sdU, fdU);
+        plasma5_explicit_cell<NS>(a, kf, dt, fU, sU, sdU, fdU, rc);
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -1035,7 +1038,8 @@ __global__ void k_plasma_dt(Geo g, IBox box, SourceArgs a, double* part) {
         decode(box, t, i, j, k);
         const long c = g.at(i, j, k);
         const double Bx = a.f_U[c + F_BX * g.sc], By = a.f_U[c + F_BY * g.sc], Bz = a.f_U[c + F_BZ * g.sc];
-        for (int n = 0; n < a.n_species; ++n) dt = cell_plasma_dt(a.Larmor, a.Debye, Bx, By, Bz, a.sp_U[n][c], a.r[n], dt);
+        for (int n = 0; n < a.n_species; ++n)
+            dt = cell_plasma_dt(a.Larmor, a.Debye, Bx, By, Bz, a.sp_U[n][c], species_r(g, a, n, c, a.sp_U[n][c]), dt);
     }
     block_reduce_store<false>(dt, part);
 }

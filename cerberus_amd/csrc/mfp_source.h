@@ -26,9 +26,11 @@ __host__ __device__ static inline SourceCoef source_coef(const SourceArgs& a, do
 // Lorentz::calc_time_derivative (MFP_lorentz.cpp:129-189).  fU: field comps,
 // sU[n]: species comps {rho,mx,my,mz,E}.  Outputs are the increments.
 // (a: SourceArgs, or any type with n_species, r[], Larmor, lightspeed — ProArgs below)
+// rc: charge / mass of this cell's species where a species is a mixture (species_r below); nullptr: a.r
 template <int MAXS, class Args>
 CMFP_DEV void plasma5_explicit_cell(const Args& a, const SourceCoef& kf, double dt, const double* fU,
-                                    const double (*sU)[5], double (*sdU)[4], double* fdU /*Dx,Dy,Dz,phi,psi*/) {
+                                    const double (*sU)[5], double (*sdU)[4], double* fdU /*Dx,Dy,Dz,phi,psi*/,
+                                    const double* rc = nullptr) {
     // FAST: no contraction left to the compiler here — the fused multiply-adds are written out, so that every
     // inlined copy of this function (the marching kernels hold several) rounds alike and a cell's result does not
     // depend on which launch, segment or row parity it falls in.  (STRICT builds never contract.)
@@ -42,7 +44,7 @@ CMFP_DEV void plasma5_explicit_cell(const Args& a, const SourceCoef& kf, double 
     for (int n = 0; n < MAXS; ++n) {
         if (n < a.n_species) {
             const double rho = sU[n][0], mx = sU[n][1], my = sU[n][2], mz = sU[n][3];
-            const double r = a.r[n];
+            const double r = rc ? rc[n] : a.r[n];
 #ifdef CMFP_FASTMATH
             charge_density = fma(rho, r, charge_density);
             current_x = fma(r, mx, current_x);
@@ -81,6 +83,27 @@ CMFP_DEV void plasma5_explicit_cell(const Args& a, const SourceCoef& kf, double 
     fdU[3] = -fU[F_PHI] * kf.f3 + kf.f2 * charge_density;
     fdU[4] = -fU[F_PSI] * kf.f3;
 #endif
+}
+
+// r = q / m of species s at the cell with plane offset c (MFP_plasma5.cpp:199-202): the constants, or for a mixture
+// get_charge_from_cons / get_mass_from_cons (MFP_hydro_gas.cpp:72-96,123-150) from alpha_i = tracer_i / rho
+CMFP_DEV double species_r(const Geo& g, const SourceArgs& a, int s, long c, double rho) {
+    const cmfp::SpeciesMix& M = a.mix[s];
+    if (M.nt == 0) return a.r[s];
+    double S_aq = 0.0, S_am = 0.0, S_a = 0.0;
+    for (int i = 0; i < 2; ++i)
+        if (i < M.nt) {
+            double al = f_div(a.sp_U[s][c + (5 + i) * g.sc], rho);
+            al = (al < 0.0) ? 0.0 : ((1.0 < al) ? 1.0 : al);
+            S_aq += f_div(al * M.q[i], M.m[i]);
+            S_am += f_div(al, M.m[i]);
+            S_a += al;
+        }
+    S_aq += f_div((1.0 - S_a) * M.q[M.nt], M.m[M.nt]);
+    S_am += f_div(1.0 - S_a, M.m[M.nt]);
+    const double m = (M.flags & 1) ? f_div(1.0, S_am) : M.m[0];
+    const double q = (M.flags & 2) ? f_div(S_aq, S_am) : M.q[0];
+    return q / m;
 }
 
 // per-cell contributions

@@ -98,6 +98,14 @@ struct CollArgs {
     int* err;                             // device flag: primitive values outside of physical bounds
 };
 
+// a species that is a mixture (cmfp_state_desc::mixture): mass and charge of a cell follow its mass fractions
+// (HydroGas::get_mass_from_cons / get_charge_from_cons, MFP_hydro_gas.cpp:72-96,123-150).  nt = 0: the constants.
+struct SpeciesMix {
+    int nt;     // tracers read (comps 5 .. 5 + nt - 1 of the species' conserved data)
+    int flags;  // bit 0: mass differs between the species, bit 1: charge differs
+    double m[3], q[3];
+};
+
 struct SourceArgs {
     int n_species;
     double* sp_U[4];   // species conserved data read
@@ -119,6 +127,7 @@ struct SourceArgs {
     unsigned long long* out_speed[4];  // final words
     unsigned long long* out_dt;
     CollArgs coll;  // a collisions_rambo action over the same species, evaluated with this source (fused step)
+    SpeciesMix mix[4];  // stage-by-stage kernels only (a state with tracers never runs fused)
 };
 
 // Strang source stage C evaluated by the last CTU kernel of the step (the field's) on the cells it updates

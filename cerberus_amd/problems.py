@@ -96,10 +96,10 @@ def with_tracers(cfg, state, alphas):
     return cfg
 
 
-def with_mixture(cfg, state, alphas, masses, gammas):
-    """Makes hydro state `state` a mixture of len(alphas) + 1 species of the given masses and gammas
-    (ThermallyPerfectGas with mass_const / gamma_const false, MFP_thermally_perfect_gas.cpp:32-34):
-    value.alpha = mass fractions of all species but the last."""
+def with_mixture(cfg, state, alphas, masses, gammas, charges=None):
+    """Makes hydro state `state` a mixture of len(alphas) + 1 species of the given masses, gammas and charges
+    (ThermallyPerfectGas with mass_const / gamma_const / charge_const false, MFP_thermally_perfect_gas.cpp:32-34;
+    charges default to the state's): value.alpha = mass fractions of all species but the last."""
     sd = cfg["states"][state]
     n = len(alphas) + 1
     if len(masses) != n or len(gammas) != n:
@@ -107,7 +107,9 @@ def with_mixture(cfg, state, alphas, masses, gammas):
     gas = sd["gas"]
     q = gas["charge"]
     gas["mass"], gas["gamma"] = [float(m) for m in masses], [float(g) for g in gammas]
-    gas["charge"] = [q[0] if isinstance(q, (list, tuple)) else q] * n
+    gas["charge"] = [float(x) for x in charges] if charges is not None else [q[0] if isinstance(q, (list, tuple)) else q] * n
+    if len(gas["charge"]) != n:
+        raise ValueError("one charge per species")
     sd["value"]["alpha"] = list(alphas)
     return cfg
 

@@ -154,12 +154,15 @@ typedef struct {
      * _from_cons, get_cp_*, MFP_thermally_perfect_gas.cpp:51-177; HydroGas::get_mass_from_*, MFP_hydro_gas.cpp:50-96):
      * mixture != 0 reads species_mass / species_gamma [0 .. n_tracers] (mass, gamma above = species 0) and gamma,
      * mass of a cell follow its mass fractions alpha_i = tracer_i / rho, the last species taking 1 - sum(alpha).
-     * Built for the transport of the state (CTU / RK2 / euler updates and its dt limit, stage-by-stage kernels):
-     * a mixture state in a source action, with viscosity or with Dirichlet face data is refused by cmfp_create /
-     * cmfp_set_face_values (species charges, which only sources read, are not carried). */
+     * The plasma5 / Lorentz sources and the plasma dt limit read mass and charge of a cell the same way
+     * (get_mass_from_cons / get_charge_from_cons, MFP_plasma5.cpp:199-202,364-365,544-545; species_charge).
+     * Built on the stage-by-stage kernels (CTU / RK2 / euler updates, sources, dt limits); a mixture state in a
+     * collisions_rambo or elliptic action, with viscosity or with Dirichlet face data is refused by cmfp_create /
+     * cmfp_state_set_face_values / cmfp_elliptic_project. */
     int mixture;
     double species_mass[CMFP_MAX_TRACERS + 1];
     double species_gamma[CMFP_MAX_TRACERS + 1];
+    double species_charge[CMFP_MAX_TRACERS + 1];
 } cmfp_state_desc;
 
 /* One action, in sorted-name order (MFP_config.cpp:261-291). */

@@ -19,7 +19,7 @@
 // (AMReX fab_filcc, source absent) and the time integrator glue have no
 // reference fixture: for those, PARITY IS UNPINNED by the reference.
 //
-// Restrictions: mixtures (species of different mass / gamma) in the transport only, no EB,
+// Restrictions: mixtures (species of different mass / charge / gamma) not in collisions / viscous terms, no EB,
 // no Lua inflow / dynamic functions, no viscous terms, single AMR level.
 
 #include "../include/cerberus_mfp.h"
@@ -229,8 +229,8 @@ static inline Real clamp01(Real a) { return (a < 0.0) ? 0.0 : ((1.0 < a) ? 1.0 :
 struct Gas {
     Real mass, charge, gamma;  // species 0
     int nt = 0;                // n_tracers = n_species - 1
-    bool mass_const = true, gamma_const = true;
-    Real sm[CMFP_MAX_TRACERS + 1] = {0}, sg[CMFP_MAX_TRACERS + 1] = {0};  // per-species mass, gamma
+    bool mass_const = true, gamma_const = true, charge_const = true;
+    Real sm[CMFP_MAX_TRACERS + 1] = {0}, sg[CMFP_MAX_TRACERS + 1] = {0}, sq[CMFP_MAX_TRACERS + 1] = {0};  // per species
     Real cp() const { return gamma / (mass * (gamma - 1)); }  // :127
     // get_gamma_from_prim :51-83 (alpha: the nt mass fractions)
     Real gamma_from_alpha(const Real* alpha) const {
@@ -275,6 +275,27 @@ struct Gas {
         }
         S_alphai_mi += (1.0 - S_alphas) / sm[nt];
         return 1.0 / S_alphai_mi;
+    }
+    // HydroGas::get_charge_from_prim MFP_hydro_gas.cpp:98-121
+    Real charge_from_alpha(const Real* alpha) const {
+        if (charge_const) return charge;
+        Real S_alphaiqi_mi = 0, S_alphai_mi = 0, S_alphas = 0, alphai;
+        for (int i = 0; i < nt; ++i) {
+            alphai = clamp01(alpha[i]);
+            S_alphaiqi_mi += alphai * sq[i] / sm[i];
+            S_alphai_mi += alphai / sm[i];
+            S_alphas += alphai;
+        }
+        S_alphaiqi_mi += (1.0 - S_alphas) * sq[nt] / sm[nt];
+        S_alphai_mi += (1.0 - S_alphas) / sm[nt];
+        return S_alphaiqi_mi / S_alphai_mi;
+    }
+    // get_mass_from_cons / get_charge_from_cons of the species' conserved values at (i, j, k)
+    template <class F> void mass_charge_from_cons(const F& U4, int i, int j, int k, Real& m, Real& q) const {
+        Real alpha[CMFP_MAX_TRACERS + 1];
+        for (int n = 0; n < nt; ++n) alpha[n] = U4(i, j, k, 5 + n) / U4(i, j, k, 0);
+        m = mass_from_alpha(alpha);
+        q = charge_from_alpha(alpha);
     }
     // the *_from_cons forms (:85-121,149-177, MFP_hydro_gas.cpp:72-96): alpha_i = U[tracer_i] / rho
     void alpha_from_cons(const Real* U, Real* alpha) const {
@@ -1620,8 +1641,7 @@ struct Sim {
                             mx = sp4(i, j, k, Xmom);
                             my = sp4(i, j, k, Ymom);
                             mz = sp4(i, j, k, Zmom);
-                            m = states[s].gas.mass;
-                            q = states[s].gas.charge;
+                            states[s].gas.mass_charge_from_cons(sp4, i, j, k, m, q);  // get_mass_from_cons, get_charge_from_cons
                             r = q / m;
                             charge_density += rho * r;
                             current_x += r * mx;
@@ -1694,8 +1714,7 @@ struct Sim {
                             mx = sp4(i, j, k, Xmom);
                             my = sp4(i, j, k, Ymom);
                             mz = sp4(i, j, k, Zmom);
-                            m = states[s].gas.mass;
-                            q = states[s].gas.charge;
+                            states[s].gas.mass_charge_from_cons(sp4, i, j, k, m, q);  // get_mass_from_cons, get_charge_from_cons
                             r = q / m;
                             Rr[n] = r;
                             charge_density += rho * r;
@@ -2076,7 +2095,8 @@ struct Sim {
                         for (int n = 0; n < n_species; ++n) {
                             const int s = A.states[n];
                             Real rho = new_data[s][b](i, j, k, Density);
-                            Real m = states[s].gas.mass, q = states[s].gas.charge;
+                            Real m, q;
+                            states[s].gas.mass_charge_from_cons(new_data[s][b], i, j, k, m, q);
                             Real r = q / m;
                             const Real omega_p = 10 * std::sqrt(rho * r * r / D2) / (2 * PI);
                             if (omega_p > 0) dt = std::min(dt, 1 / omega_p);
@@ -2108,6 +2128,8 @@ static void setup_state(StateDef& S, const cmfp_state_desc& d, const cmfp_params
         for (int i = 0; i <= d.n_tracers; ++i) {  // mass_const / gamma_const MFP_thermally_perfect_gas.cpp:32-34
             S.gas.sm[i] = d.mixture ? d.species_mass[i] : d.mass;
             S.gas.sg[i] = d.mixture ? d.species_gamma[i] : d.gamma;
+            S.gas.sq[i] = d.mixture ? d.species_charge[i] : d.charge;
+            if (S.gas.sq[i] != S.gas.sq[0]) S.gas.charge_const = false;
             if (S.gas.sm[i] != S.gas.sm[0]) S.gas.mass_const = false;
             if (S.gas.sg[i] != S.gas.sg[0]) S.gas.gamma_const = false;
         }
@@ -2234,12 +2256,12 @@ void* orc_create(const cmfp_geometry* g, const cmfp_params* p, int n_states, con
     for (int s = 0; s < n_states; ++s) setup_state(S->states[s], sd[s], *p);
     S->actions.resize(n_actions);
     for (int a = 0; a < n_actions; ++a) S->actions[a].desc = ad[a];
-    // mixtures are restated for the transport only: the sources, the viscous fluxes and the Dirichlet tables
-    // below keep the constants of species 0
+    // mixtures are restated for the transport and the plasma5 / Lorentz sources: collisions, the viscous fluxes
+    // and the Dirichlet tables below keep the constants of species 0
     for (int s = 0; s < n_states; ++s)
         if (sd[s].kind == CMFP_STATE_HYDRO && sd[s].mixture && sd[s].viscosity) flag_abort();
     for (int a = 0; a < n_actions; ++a)
-        if (ad[a].kind != CMFP_ACTION_CTU)
+        if (ad[a].kind == CMFP_ACTION_COLLISIONS_RAMBO)
             for (int n = 0; n < ad[a].n_states; ++n)
                 if (sd[ad[a].states[n]].kind == CMFP_STATE_HYDRO && sd[ad[a].states[n]].mixture) flag_abort();
     // chop the domain into boxes of at most max_grid cells per side

@@ -91,9 +91,8 @@ def test_unsupported_options_fail_loudly():
     cfg = problems.kelvin_helmholtz_2d(16)
     cfg["states"]["fluid"]["gas"]["mass"] = [1.0, 2.0]            # a mixture: built for the transport (test_mixture.py)
     assert config.Problem(cfg).state_descs()[0].mixture == 1
-    cfg["states"]["fluid"]["gas"]["charge"] = [0.0, 1.0]          # species of different charge: read by sources only
-    with pytest.raises(NotImplementedError):
-        config.Problem(cfg).state_descs()
+    cfg["states"]["fluid"]["gas"]["charge"] = [0.0, 1.0]          # species of different charge: read by the sources
+    assert list(config.Problem(cfg).state_descs()[0].species_charge)[:2] == [0.0, 1.0]
     cfg["states"]["fluid"]["gas"]["charge"] = [0.0, 0.0, 0.0]     # MFP_thermally_perfect_gas.cpp:36-39
     with pytest.raises(ValueError):
         config.Problem(cfg).state_descs()

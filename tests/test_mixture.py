@@ -95,12 +95,21 @@ def test_mixture_descriptor_and_initial_data():
     assert g.min() < 1.3 and g.max() > 1.6
 
 
+# ions of two kinds in one state (same charge, different mass; different charge and mass), electrons of two "kinds"
+PLASMA_MIXES = [{"ion": ([0.4], [1.0, 1.5], [1.0, 1.0])},
+                {"ion": ([0.5], [1.0, 4.0], [1.0, 2.0]), "electron": ([0.25], [0.04, 0.08], [-1.0, -1.0])}]
+
+
+@pytest.mark.parametrize("mix", PLASMA_MIXES)
+def test_mixture_plasma_frequency_oracle(oracle, mix):
+    """the plasma5 source reads charge / mass of a cell from its mass fractions (MFP_plasma5.cpp:199-202): the
+    Langmuir oscillation of a uniform plasma with mixture species runs at the plasma frequency of the mixture's r"""
+    import test_physics_pins as pp
+    err, back, uniform = pp.check_langmuir(lambda P: pp.OracleRunner(oracle, P), mix=mix)
+    assert err <= pp.OSC_TOL and back <= pp.OSC_TOL and uniform <= 1e-12, (err, back, uniform)
+
+
 def test_mixture_refusals():
-    cfg = problems.orszag_tang_two_fluid_2d(16)
-    problems.with_mixture(cfg, "ion", [0.5], [1.0, 2.0], [5 / 3, 1.4])
-    cfg["states"]["ion"]["gas"]["charge"] = [1.0, 2.0]
-    with pytest.raises(NotImplementedError):
-        config.Problem(cfg).state_descs()
     cfg = problems.viscous_vortex_2d(16)
     problems.with_mixture(cfg, next(iter(cfg["states"])), [0.5], [1.0, 2.0], [1.4, 1.4])
     with pytest.raises(NotImplementedError):
@@ -183,10 +192,60 @@ def test_mixture_sound_speed_gpu(alpha, masses, gammas, mode):
     assert err <= ACOUSTIC_TOL and drift <= 1e-12, (err, drift)
 
 
+def _plasma_cases():
+    out = []
+    wave = lambda d: 0.5 + 0.3 * np.sin(d["x"]) * np.cos(d["y"])
+    for solver, source, scheme in (("explicit", "plasma5", "strang"), ("implicit", "plasma5", "strang"),
+                                   ("explicit", "Lorentz", "strang"), ("explicit", "plasma5", "RK2")):
+        cfg = problems.orszag_tang_two_fluid_2d(24, solver=solver, source=source)
+        cfg["time_integration_scheme"] = scheme
+        problems.with_mixture(cfg, "ion", [wave], [1.0, 3.0], [5 / 3, 1.4], [1.0, 2.0])
+        if solver == "explicit" and scheme == "strang" and source == "plasma5":
+            problems.with_mixture(cfg, "electron", [0.3, wave], [0.01, 0.02, 0.04], [5 / 3] * 3, [-1.0, -1.0, -2.0])
+        out.append((f"ot-{source}-{solver}-{scheme}", cfg))
+    cfg = problems.richtmyer_meshkov_3d(16, 8, 8)
+    problems.with_mixture(cfg, "ion", [lambda d: (d["x"] > 0) * 0.8 + 0.1], [1.0, 2.0], [5 / 3, 5 / 3])
+    out.append(("rmi3d", cfg))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg", _plasma_cases(), ids=[c[0] for c in _plasma_cases()])
+def test_mixture_in_sources_parity(oracle, name, cfg):
+    """mixture species in plasma5 (explicit, implicit) / Lorentz and the plasma dt limit: per-cell charge / mass.
+    STRICT bit-identical to the oracle with the dt sequence (implicit: 1e-12, block elimination), FAST 1e-12."""
+    for mode, tol in ((abi.FP_STRICT, 0.0), (abi.FP_FAST, 1e-12)):
+        P = config.Problem(cfg, fp_mode=mode)
+        ref = oracle.OracleSim(P)
+        dts_ref = ref.run(5)
+        m = _gpu(P)
+        dts = m.run(5)
+        assert m.last_advance_path() == 0
+        exact = tol == 0.0 and "implicit" not in name
+        if exact:
+            assert dts == dts_ref, name
+        for s in range(m.n_states):
+            got, want = m.download(s), ref.get_state(s)
+            if exact:
+                assert np.array_equal(got, want), (name, s, rel_linf(got, want))
+            else:
+                assert rel_linf(got, want) <= max(tol, 1e-12), (name, mode, s)
+        m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [abi.FP_STRICT, abi.FP_FAST])
+@pytest.mark.parametrize("mix", PLASMA_MIXES)
+def test_mixture_plasma_frequency_gpu(mix, mode):
+    import test_physics_pins as pp
+    err, back, uniform = pp.check_langmuir(lambda P: pp.GpuRunner(config.Problem(P.cfg, fp_mode=mode)), mix=mix)
+    assert err <= pp.OSC_TOL and back <= pp.OSC_TOL and uniform <= 1e-12, (err, back, uniform)
+
+
 @pytest.mark.gpu
 def test_mixture_refusals_of_the_library():
-    """a mixture in a source action or with Dirichlet face data: CMFP_ERR_INVALID, nothing silently approximated"""
-    cfg = problems.orszag_tang_two_fluid_2d(16)
+    """a mixture in a collisions action or with Dirichlet face data: CMFP_ERR_INVALID, nothing silently approximated"""
+    cfg = problems.orszag_tang_two_fluid_2d(16, collisions=True)
     problems.with_mixture(cfg, "ion", [0.5], [1.0, 2.0], [5 / 3, 1.4])
     with pytest.raises(lib.CmfpError) as e:
         _gpu(config.Problem(cfg))

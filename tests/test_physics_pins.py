@@ -163,13 +163,26 @@ def test_cleaning_wave_gpu(mode):
 OSC_TOL = 5e-4        # normalised current / momentum over one period against the analytic cosine: 0.05 %
 
 
-def check_langmuir(make, **kw):
+def mixture_r(gas, alpha):
+    """charge / mass of a gas at mass fractions alpha (all species but the last): HydroGas::get_charge_from_prim over
+    get_mass_from_prim (MFP_hydro_gas.cpp:50-121), written out independently of the library and the oracle"""
+    if not isinstance(gas["mass"], (list, tuple)):
+        return gas["charge"] / gas["mass"]
+    al = list(alpha) + [1.0 - sum(alpha)]
+    n_over_rho = sum(a / m for a, m in zip(al, gas["mass"]))              # 1 / m_mix
+    q = sum(a * q / m for a, m, q in zip(al, gas["mass"], gas["charge"])) / n_over_rho
+    return q * n_over_rho
+
+
+def check_langmuir(make, mix=None, **kw):
     cfg = problems.uniform_plasma_2d(8, "plasma5", u0=1e-3, **kw)
+    for nm, (alphas, masses, charges) in (mix or {}).items():
+        problems.with_mixture(cfg, nm, alphas, masses, [5 / 3] * len(masses), charges)
     P = config.Problem(cfg)
     run = make(P)
     D = P.ref["Debye"]
     sp = [(i, cfg["states"][nm]["gas"]) for i, nm in enumerate(P.state_names) if cfg["states"][nm]["type"] == "hydro"]
-    r = {i: g["charge"] / g["mass"] for i, g in sp}
+    r = {i: mixture_r(g, cfg["states"][P.state_names[i]]["value"].get("alpha", [])) for i, g in sp}
     rho = {i: float(run.state(i)[0].mean()) for i, _ in sp}
     wp = math.sqrt(sum(rho[i] * r[i] ** 2 for i, _ in sp)) / D
     J = lambda: sum(r[i] * float(run.state(i)[1].mean()) for i, _ in sp)
