@@ -103,6 +103,35 @@ def gas_gamma_from_alpha(gas, alpha):
     return s_cp / s_cv
 
 
+def gas_cp_from_alpha(gas, alpha):
+    """ThermallyPerfectGas::get_cp_from_prim (MFP_thermally_perfect_gas.cpp:123-147) on arrays."""
+    g, m = gas_list(gas, "gamma"), gas_list(gas, "mass")
+    if all(x == g[0] for x in g) and all(x == m[0] for x in m):
+        return g[0] / (m[0] * (g[0] - 1))
+    s_cp = s_a = 0.0
+    for i, a in enumerate(alpha):
+        a = np.clip(a, 0.0, 1.0)
+        s_a = s_a + a
+        s_cp = s_cp + a * (g[i] / (m[i] * (g[i] - 1.0)))
+    return s_cp + (1.0 - s_a) * (g[-1] / (m[-1] * (g[-1] - 1.0)))
+
+
+def gas_charge_from_alpha(gas, alpha):
+    """HydroGas::get_charge_from_prim (MFP_hydro_gas.cpp:98-121) on arrays."""
+    q, m = gas_list(gas, "charge"), gas_list(gas, "mass")
+    if all(x == q[0] for x in q):
+        return q[0]
+    s_q = s_m = s_a = 0.0
+    for i, a in enumerate(alpha):
+        a = np.clip(a, 0.0, 1.0)
+        s_q = s_q + a * q[i] / m[i]
+        s_m = s_m + a / m[i]
+        s_a = s_a + a
+    s_q = s_q + (1.0 - s_a) * q[-1] / m[-1]
+    s_m = s_m + (1.0 - s_a) / m[-1]
+    return s_q / s_m
+
+
 def gas_mass_from_alpha(gas, alpha):
     """HydroGas::get_mass_from_prim (MFP_hydro_gas.cpp:50-70) on arrays."""
     m = gas_list(gas, "mass")

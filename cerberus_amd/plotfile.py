@@ -38,7 +38,10 @@ def state_plot_names(P, s):
     """get_plot_output_names(): HydroState MFP_hydro.cpp:569-589, FieldState MFP_field.cpp:68-79."""
     sd = P.cfg["states"][P.state_names[s]]
     if sd["type"] == "hydro":
-        return HYDRO_CONS + HYDRO_PRIM + ["charge", "mass", "gamma"]
+        names = HYDRO_CONS + HYDRO_PRIM + ["charge", "mass", "gamma"]
+        for i in range(config.gas_n_tracers(sd["gas"])):     # get_multicomp_name, MFP_hydro.cpp:583-586
+            names += [f"tracer_{i}", f"alpha_{i}"]
+        return names
     return list(FIELD_CONS)
 
 
@@ -62,21 +65,27 @@ def state_plot_data(P, s, U):
             out[f"{v}-{sname}"] = U[n]
         return out
     gas = sd["gas"]
-    mass, charge, gamma = (config.gas_scalar(gas, k) for k in ("mass", "charge", "gamma"))
+    nt = config.gas_n_tracers(gas)
     ez = float(sd.get("effective_zero", 1e-14))
     ok = U[0] >= ez                                   # :700 cells below effective_zero stay 0
     rho = np.where(ok, U[0], 1.0)
+    # gas constants of the cell: get_*_from_cons with alpha_i = tracer_i / rho (numbers where the species agree)
+    ac = [U[5 + i] / rho for i in range(nt)]
+    mass, charge = config.gas_mass_from_alpha(gas, ac), config.gas_charge_from_alpha(gas, ac)
+    gamma, cp = config.gas_gamma_from_alpha(gas, ac), config.gas_cp_from_alpha(gas, ac)
     # ThermallyPerfectGas::cons2prim, MFP_thermally_perfect_gas.cpp:180-218
     rhoinv = 1.0 / rho
     u, v, w = U[1] * rhoinv, U[2] * rhoinv, U[3] * rhoinv
     ke = 0.5 * rho * (u * u + v * v + w * w)
     p = (U[4] - ke) * (gamma - 1)
     T = p * rhoinv * mass
-    cp = gamma / (mass * (gamma - 1))
     one = np.ones_like(rho)
     vals = dict(zip(HYDRO_CONS, U[:5]))
     vals.update({"x_vel": u, "y_vel": v, "z_vel": w, "p": p, "T": T, "gamma": gamma * one, "cp": cp * one,
                  "charge": charge * one, "mass": mass * one})
+    for i in range(nt):                               # :622-645, alpha = tracer * rhoinv (:212-214)
+        vals[f"tracer_{i}"] = U[5 + i]
+        vals[f"alpha_{i}"] = U[5 + i] * rhoinv
     for k, a in vals.items():
         out[f"{k}-{sname}"] = np.where(ok, a, 0.0)
     return out
@@ -96,7 +105,8 @@ def state_info(P, s):
         gas = sd["gas"]
         js["cons_names"] = list(HYDRO_CONS)
         nsp = config.gas_n_tracers(gas) + 1
-        js["gas"] = {k: [config.gas_scalar(gas, k)] * nsp for k in ("mass", "charge", "gamma")}
+        js["gas"] = {k: config.gas_list(gas, k) for k in ("mass", "charge", "gamma")}
+        assert all(len(v) == nsp for v in js["gas"].values())
         js["gas"].update({"comp_names": [], "type": gas.get("type", "thermally_perfect")})
         if "viscosity" in sd:
             js["viscosity"] = dict(sd["viscosity"])

@@ -75,6 +75,33 @@ def test_plotfile_layout_roundtrip(tmp_path, mgs):
     assert abs(info["Debye"] - 0.01) < 1e-15 and info["lightspeed"] == 20.0
 
 
+def test_plotfile_of_a_mixture(tmp_path):
+    """tracer_i / alpha_i variables (MFP_hydro.cpp:583-586) and the per-cell mass, charge, gamma, cp, T of a gas of
+    several species (get_plot_output :702-717)"""
+    cfg = problems.shock_bubble_2d(32, 16, species=3)
+    cfg["states"]["fluid"]["gas"]["charge"] = [0.0, 1.0, 2.0]
+    P = config.Problem(cfg)
+    U = P.initial_data(0)
+    d = str(tmp_path / "plt00000")
+    names = plotfile.write_plotfile(d, P, [U], time=0.0, step=0)
+    for v in ("tracer_0-fluid", "alpha_1-fluid", "mass-fluid", "gamma-fluid", "cp-fluid", "charge-fluid"):
+        assert v in names
+    assert np.array_equal(_read_back(d, "tracer_1-fluid")[2], U[6, 0])
+    a0, a1 = U[5, 0] / U[0, 0], U[6, 0] / U[0, 0]
+    al = [a0, a1, 1 - (a0 + a1)]
+    m, g, q = [1.0, 2.0, 0.138], [1.4, 1.1, 5.0 / 3.0], [0.0, 1.0, 2.0]
+    n = sum(a / mi for a, mi in zip(al, m))
+    np.testing.assert_allclose(_read_back(d, "mass-fluid")[2], 1 / n, rtol=1e-14)
+    np.testing.assert_allclose(_read_back(d, "charge-fluid")[2], sum(a * qi / mi for a, mi, qi in zip(al, m, q)) / n, rtol=1e-13)
+    cp = sum(a * gi / (mi * (gi - 1)) for a, mi, gi in zip(al, m, g))
+    cv = sum(a / (mi * (gi - 1)) for a, mi, gi in zip(al, m, g))
+    np.testing.assert_allclose(_read_back(d, "gamma-fluid")[2], cp / cv, rtol=1e-14)
+    np.testing.assert_allclose(_read_back(d, "cp-fluid")[2], cp, rtol=1e-14)
+    np.testing.assert_allclose(_read_back(d, "p-fluid")[2][:, 20:], 1.0, rtol=1e-13)      # ahead of the shock
+    info = json.load(open(os.path.join(d, "info")))
+    assert info["state_0"]["gas"]["mass"] == m and info["state_0"]["gas"]["charge"] == q
+
+
 @pytest.mark.skipif(not os.path.exists(REF_READER), reason="reference tree not present (GPU box)")
 def test_reference_reader_reads_our_plotfile(tmp_path):
     """The reference's post-processing reader parses the plotfile and returns the data bit for bit."""
