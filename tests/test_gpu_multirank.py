@@ -57,6 +57,12 @@ def _cfg(which):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from test_oracle import inflow_cfg
         return inflow_cfg(32, 16)
+    if which == "mix2d":        # three-gas mixture, walls in y and outflow in x cut into the blocks (stage-by-stage kernels)
+        return problems.shock_bubble_2d(64, 32, species=3)
+    if which == "mixot":        # two-fluid with mixture ions: per-cell charge / mass in the sources on every rank
+        cfg = problems.orszag_tang_two_fluid_2d(32)
+        return problems.with_mixture(cfg, "ion", [lambda d: 0.5 + 0.3 * np.sin(d["x"]) * np.cos(d["y"])], [1.0, 3.0],
+                                     [5 / 3, 1.4], [1.0, 2.0])
     if which == "gem":
         return problems.gem_reconnection_2d(32, 32)
     if which == "gem64":        # 2 x 4 blocks of 32 x 16 with the conducting walls on the outer ranks in y
@@ -88,7 +94,9 @@ def _free_port():
                                                  (8, "ot512", True), (8, "ot96", True), (8, "gem64", True), (8, "rmi3d24", True),
                                                  # FAST arithmetic: source stage A as the CTU kernels' prologue on split blocks
                                                  (2, "ot96@fast", True), (4, "ot96@fast", False), (4, "ot512@fast", True), (8, "ot512@fast", True),
-                                                 (4, "gem@fast", True), (8, "gem64@fast", True), (4, "rmi3d24@fast", True)] +
+                                                 (4, "gem@fast", True), (8, "gem64@fast", True), (4, "rmi3d24@fast", True),
+                                                 # mixtures (gamma, mass, charge of a cell from its mass fractions)
+                                                 (4, "mix2d", True), (2, "mixot", False), (4, "mixot@fast", True)] +
                                                 [(2 + 2 * (k % 2), f"rand{k}", k % 3 != 0) for k in range(10)])
 def test_decomposed_run_equals_single_rank(world, which, batched):
     import torch.multiprocessing as mp
@@ -124,7 +132,7 @@ def test_decomposed_run_equals_single_rank(world, which, batched):
         else:
             assert o["dts"] == dts
         assert o["fusion"] == fusion
-        if not which.startswith("rand"):
+        if not which.startswith(("rand", "mix")):
             assert o["fused"]           # (since round 2 also the inflow case: marching kernel with the face tables)
             assert o["device_dt"]     # cmfp_advance_steps with the cross-rank dt minimum on the device
         lo, n = o["lo"], o["n"]

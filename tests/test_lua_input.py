@@ -191,3 +191,44 @@ def test_every_shipped_inputs_file_loads_or_is_refused_for_a_stated_reason():
         assert P.state_names and isinstance(info["ignored"], list)
         loaded += 1
     assert loaded == len(files) - len(expected_failure)
+
+
+MIXTURE_SCRIPT = r"""
+-- a gas of three species: mass = {...}, charge = {...}, gamma = {...} (set_values, MFP_thermally_perfect_gas.cpp:24-26)
+-- and value.alpha = the mass fractions of all but the last (MFP_hydro.cpp:148)
+local function bubble(dat)
+  local r = math.sqrt((dat.x - 0.1) ^ 2 + (dat.y - 0.5) ^ 2)
+  return 0.5 * (1 + math.tanh((r - 0.3) / 0.05))
+end
+lightspeed = 1.0
+skin_depth = 1.0
+cfl = 0.4
+states = {
+  gas = { type = 'hydro',
+          gas = { type = 'thermally_perfect', mass = { 1.0, 2.0, 0.138 }, charge = { 0, 0, 0 }, gamma = { 1.4, 1.1, 5 / 3 } },
+          reconstruction = 'vanLeer', flux = 'HLLC',
+          value = { rho = function(dat) return 0.138 + (1 - 0.138) * bubble(dat) end, p = 1.0,
+                    alpha = { function(dat) return 0.9 * bubble(dat) end, 0.05 } } },
+}
+actions = { fluxes = { type = 'CTU', corner_transport = true, states = { 'gas' } } }
+"""
+
+
+def test_mixture_gas_from_lua(oracle):
+    """the reference's list form of mass / charge / gamma and value.alpha load into a mixture descriptor and run"""
+    geom = dict(GEOM, n_cell=[16, 8], is_periodic=[1, 1])
+    cfg, _ = lua_input.load_lua(MIXTURE_SCRIPT, geom)
+    P = config.Problem(cfg)
+    d = P.state_descs()[0]
+    assert d.mixture == 1 and d.n_tracers == 2 and list(d.species_gamma) == [1.4, 1.1, 5 / 3]
+    U = P.initial_data(0)
+    dat = P.cell_centres()
+    r = np.sqrt((dat["x"] - 0.1) ** 2 + (dat["y"] - 0.5) ** 2)
+    b = 0.5 * (1 + np.tanh((r - 0.3) / 0.05))
+    np.testing.assert_allclose(U[5] / U[0], 0.9 * b, rtol=1e-13)
+    np.testing.assert_allclose(U[6] / U[0], 0.05, rtol=1e-13)
+    g = config.gas_gamma_from_alpha(cfg["states"]["gas"]["gas"], [U[5] / U[0], U[6] / U[0]])
+    np.testing.assert_allclose((U[4]) * (g - 1), 1.0, rtol=1e-13)          # at rest: nrg = p / (gamma_mix - 1)
+    sim = oracle.OracleSim(P)
+    dts = sim.run(3)
+    assert all(x > 0 for x in dts) and np.isfinite(sim.get_state(0)).all()
