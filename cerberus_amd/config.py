@@ -219,8 +219,6 @@ class Problem:
                         d.species_gamma[k] = x
                     for k, x in enumerate(gas_list(gas, "charge")):
                         d.species_charge[k] = x
-                    if sd.get("viscosity"):
-                        raise NotImplementedError("viscous fluxes of a mixture are not built")
                 d.flux = abi.FLUX[sd["flux"]]
                 if d.flux == abi.FLUX["RankineHugoniot"]:
                     raise ValueError("hydro state with a field flux")

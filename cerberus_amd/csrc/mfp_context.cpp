@@ -1254,8 +1254,6 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
                 return fail(c, CMFP_ERR_INVALID, "n_tracers must be 0..2");
             if (states[s].n_tracers && sp.flux == CMFP_FLUX_HYBRID_HLL)
                 return fail(c, CMFP_ERR_INVALID, "HLLE/HLLC with tracers: the reference leaves the blended tracer fluxes undefined (MFP_hybrid_hll.cpp:43-45)");
-            if (states[s].n_tracers && states[s].viscosity)
-                return fail(c, CMFP_ERR_INVALID, "viscous fluxes with tracers are not supported");
             sp.nc = sp.nq = 5 + states[s].n_tracers;
             sp.hp.nt = states[s].n_tracers;
             if (sp.flux != CMFP_FLUX_HLLC && sp.flux != CMFP_FLUX_HLLE && sp.flux != CMFP_FLUX_HYBRID_HLL)
@@ -1268,7 +1266,6 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
             if (states[s].mixture) {
                 // species of different mass / gamma (mass_const / gamma_const false, MFP_thermally_perfect_gas.cpp:32-34)
                 const int nsp = states[s].n_tracers + 1;
-                if (states[s].viscosity) return fail(c, CMFP_ERR_INVALID, "viscous fluxes of a mixture are not built");
                 for (int i = 0; i < nsp; ++i) {
                     const double m = states[s].species_mass[i], gm = states[s].species_gamma[i];
                     if (!(m != 0.0) || !(gm != 0.0) || gm == 1.0) return fail(c, CMFP_ERR_INVALID, "mass and gamma cannot be 0");
@@ -1767,7 +1764,10 @@ int cmfp_state_set_face_values(cmfp_context* c, int s, int dim, int side, int pr
         return fail(c, CMFP_ERR_INVALID, "bad state / face");
     StateRT& st = c->states[s];
     if (prim < 0 || prim >= st.sp.nq) return fail(c, CMFP_ERR_INVALID, "bad primitive index");
-    if (st.sp.kind == CMFP_STATE_HYDRO && st.sp.hp.mix) return fail(c, CMFP_ERR_INVALID, "Dirichlet face data of a mixture are not built");
+    // (a mixture's carried Gamma entry, slot 5 + nt, takes no table: the reference's face data name rho, velocities,
+    // p and alpha, and gamma follows alpha)
+    if (st.sp.kind == CMFP_STATE_HYDRO && st.sp.hp.mix && prim >= st.sp.nc)
+        return fail(c, CMFP_ERR_INVALID, "bad primitive index");
     if (c->geom.is_periodic[dim]) return fail(c, CMFP_ERR_INVALID, "Dirichlet data on a periodic face");
     if ((cell_values == nullptr) != (face_values == nullptr)) return fail(c, CMFP_ERR_INVALID, "cell and face values go together");
     if (!cell_values) {

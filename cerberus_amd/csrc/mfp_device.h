@@ -342,6 +342,23 @@ CMFP_DEV GasP mix_gas(const cmfp::HydroParams& hp, const double* alpha) {
     return G;
 }
 
+// get_cp_from_prim MFP_thermally_perfect_gas.cpp:123-147 (hp.mix != 0: the species differ in gamma or mass)
+CMFP_DEV double mix_cp(const cmfp::HydroParams& hp, const double* alpha) {
+    double S_a = 0.0, S_cp = 0.0;
+    if (hp.nt > 0) {
+        const double a0 = mix_clamp01(alpha[0]);
+        S_a += a0;
+        S_cp += a0 * hp.sp_cp[0];
+    }
+    if (hp.nt > 1) {
+        const double a1 = mix_clamp01(alpha[1]);
+        S_a += a1;
+        S_cp += a1 * hp.sp_cp[1];
+    }
+    S_cp += (1.0 - S_a) * (hp.nt > 1 ? hp.sp_cp[2] : hp.sp_cp[1]);
+    return S_cp;
+}
+
 // ------------------------------------------------------------ Riemann: hydro
 // What the passive-scalar (tracer) fluxes need from a hydro Riemann solve: HLLC (MFP_hllc.cpp:100,
 // 111-137,147-173,183): side K the flux was taken from, its normal velocity and density, and in a

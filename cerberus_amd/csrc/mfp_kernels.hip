@@ -908,7 +908,7 @@ __global__ __launch_bounds__(TPB) void k_source_rk2(Geo g, IBox box, SourceArgs 
 // ThermallyPerfectGas::cons2prim (so u, v, w, T equal the reference's primitive array), and
 // HydroViscous::get_coeffs (MFP_hydro_viscous.cpp:145-160, 207-220, 266-279).
 struct ViscCell {
-    double u, v, w, T, mu, kappa, rho;
+    double u, v, w, T, mu, kappa, rho, gamma;
 };
 __device__ __forceinline__ double visc_mu(const ViscP& V, double T) {
     if (V.kind == 1) {  // CMFP_VISC_SUTHERLAND
@@ -918,10 +918,22 @@ __device__ __forceinline__ double visc_mu(const ViscP& V, double T) {
     if (V.kind == 2) return  /* CMFP_VISC_POWERLAW */ V.mu0 * pow(T / V.T0, V.n);
     return V.mu0;
 }
-__device__ __forceinline__ ViscCell visc_cell(const GasP& G, const ViscP& V, const double* __restrict__ U, long c, long sc) {
+__device__ __forceinline__ ViscCell visc_cell(const HydroParams& hp, const ViscP& V, const double* __restrict__ U, long c, long sc) {
     ViscCell q;
     const double rho = U[c], mx = U[c + sc], my = U[c + 2 * sc], mz = U[c + 3 * sc], ed = U[c + 4 * sc];
     const double rhoinv = 1 / rho;
+    GasP G = hp.gas;
+    double cp_mix = 0.0;
+    if (hp.mix) {  // gamma, mass from the conserved alpha (tracer / rho), cp from the primitive one (tracer * rhoinv)
+        double ac[2] = {0.0, 0.0}, ap[2] = {0.0, 0.0};
+        for (int n = 0; n < hp.nt; ++n) {
+            ac[n] = f_div(U[c + (5 + n) * sc], rho);
+            ap[n] = U[c + (5 + n) * sc] * rhoinv;
+        }
+        G = mix_gas(hp, ac);
+        cp_mix = mix_cp(hp, ap);
+    }
+    q.gamma = G.gamma;
     q.rho = rho;
     q.u = mx * rhoinv;
     q.v = my * rhoinv;
@@ -929,7 +941,7 @@ __device__ __forceinline__ ViscCell visc_cell(const GasP& G, const ViscP& V, con
     const double ke = 0.5 * rho * (q.u * q.u + q.v * q.v + q.w * q.w);
     const double p = (ed - ke) * (G.gamma - 1);
     q.T = p * rhoinv * G.mass;
-    const double cp = G.gamma / (G.mass * (G.gamma - 1));  // MFP_thermally_perfect_gas.cpp:127
+    const double cp = hp.mix ? cp_mix : G.gamma / (G.mass * (G.gamma - 1));  // MFP_thermally_perfect_gas.cpp:127
     q.mu = visc_mu(V, q.T);
     q.kappa = q.mu * cp / V.Pr;
     return q;
@@ -938,7 +950,7 @@ __device__ __forceinline__ ViscCell visc_cell(const GasP& G, const ViscP& V, con
 // HydroState::calc_viscous_fluxes MFP_hydro.cpp:1085-1271, one thread per face of direction D.
 // `two_thirds = 2 / 3` is integer division in the reference (:1123): the divergence term is absent.
 template <int D>
-__global__ void k_viscous(Geo g, IBox faces, GasP G, ViscP V, const double* __restrict__ U, double* __restrict__ flux) {
+__global__ void k_viscous(Geo g, IBox faces, HydroParams G, ViscP V, const double* __restrict__ U, double* __restrict__ flux) {
     int i, j, k;
     if (!decode(faces, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
     const long sc = g.sc;
@@ -993,14 +1005,14 @@ __global__ void k_viscous(Geo g, IBox faces, GasP G, ViscP V, const double* __re
 
 // HydroViscous::get_min_dt MFP_hydro_viscous.cpp:34-97, cell loop: max of calc_stability_condition
 // (:162-176, 222-236, 281-292), starting from 0
-__global__ void k_visc_stability(Geo g, IBox box, GasP G, ViscP V, const double* __restrict__ U, double* part) {
+__global__ void k_visc_stability(Geo g, IBox box, HydroParams G, ViscP V, const double* __restrict__ U, double* part) {
     const long npts = box.npts();
     double m = 0.0;
     for (long t = (long)blockIdx.x * TPB + threadIdx.x; t < npts; t += (long)gridDim.x * TPB) {
         int i, j, k;
         decode(box, t, i, j, k);
         const ViscCell q = visc_cell(G, V, U, g.at(i, j, k), g.sc);
-        const double s = (4 * q.mu * G.gamma / (V.Pr * q.rho));
+        const double s = (4 * q.mu * q.gamma / (V.Pr * q.rho));
         m = (m < s) ? s : m;
     }
     block_reduce_store<true>(m, part);
@@ -1400,15 +1412,15 @@ static void l_viscous(const Geo& g, const StatePhys& sp, int d, const double* U,
     IBox f = valid_box(g);
     f.hi[d] += 1;  // faces lo.d .. hi.d + 1 of the box (MFP_hydro.cpp:1131,1208)
     if (d == 0)
-        LAUNCH((k_viscous<0>), f.npts(), st, g, f, sp.hp.gas, sp.visc, U, flux);
+        LAUNCH((k_viscous<0>), f.npts(), st, g, f, sp.hp, sp.visc, U, flux);
     else
-        LAUNCH((k_viscous<1>), f.npts(), st, g, f, sp.hp.gas, sp.visc, U, flux);
+        LAUNCH((k_viscous<1>), f.npts(), st, g, f, sp.hp, sp.visc, U, flux);
 }
 static void l_visc_stability(const Geo& g, const StatePhys& sp, const double* U, double* part, unsigned long long* out,
                              hipStream_t st) {
     IBox b = valid_box(g);
     const unsigned nb = red_blocks(b.npts());
-    hipLaunchKernelGGL(k_visc_stability, dim3(nb), dim3(TPB), 0, st, g, b, sp.hp.gas, sp.visc, U, part);
+    hipLaunchKernelGGL(k_visc_stability, dim3(nb), dim3(TPB), 0, st, g, b, sp.hp, sp.visc, U, part);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(TPB), 0, st, part, (int)nb, 1, out);
 }
 static void l_plasma_dt(const Geo& g, const SourceArgs& a, double* part, unsigned long long* out, hipStream_t st) {

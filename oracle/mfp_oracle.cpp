@@ -770,7 +770,7 @@ static inline long tab_at(const Box& b, int i, int j, int k) {
 static void visc_coeffs(const StateDef& S, const Real* Q, Real& T, Real& mu, Real& kappa) {
     const cmfp_state_desc& d = S.desc;
     T = Q[Temp];
-    Real cp = S.gas.cp();
+    Real cp = S.gas.cp_from_alpha(Q + HP_NUM);  // get_cp_from_prim(Q)
     if (d.viscosity == CMFP_VISC_SUTHERLAND) {
         Real T_ = T / d.visc_T0;
         mu = d.visc_mu0 * T_ * sqrt(T_) * (d.visc_T0 + d.visc_S) / (T + d.visc_S);
@@ -789,8 +789,11 @@ static Real visc_stability(const StateDef& S, const Real* U) {
     Real rhoinv = 1 / rho;
     Real u = U[Xmom] * rhoinv, v = U[Ymom] * rhoinv, w = U[Zmom] * rhoinv;
     Real ke = 0.5 * rho * (u * u + v * v + w * w);
-    Real p = (U[Eden] - ke) * (S.gas.gamma - 1);
-    Real T = p * rhoinv * S.gas.mass;
+    Real alpha[CMFP_MAX_TRACERS + 1];
+    S.gas.alpha_from_cons(U, alpha);
+    const Real gam = S.gas.gamma_from_alpha(alpha);  // get_gamma_from_cons
+    Real p = (U[Eden] - ke) * (gam - 1);
+    Real T = p * rhoinv * S.gas.mass_from_alpha(alpha);
     (void)Q;
     Real mu;
     if (d.viscosity == CMFP_VISC_SUTHERLAND) {
@@ -801,7 +804,7 @@ static Real visc_stability(const StateDef& S, const Real* U) {
     } else {
         mu = d.visc_mu0;
     }
-    return (4 * mu * S.gas.gamma / (d.visc_Pr * rho));
+    return (4 * mu * gam / (d.visc_Pr * rho));
 }
 
 // HydroState::calc_viscous_fluxes MFP_hydro.cpp:1085-1329 (regular cells; 1-D and 2-D: the 3-D
@@ -812,8 +815,8 @@ static void calc_viscous_fluxes(const StateDef& S, int DIM, const Box& box, Fab*
     for (int d = 0; d < DIM; ++d) dxinv[d] = 1 / dx[d];
     const Real two_thirds = 2 / 3;
     auto coef = [&](int i, int j, int k, Real& T, Real& mu, Real& kappa) {
-        Real Q[HP_NUM];
-        for (int n = 0; n < HP_NUM; ++n) Q[n] = prim(i, j, k, n);
+        Real Q[CMFP_MAX_COMP];
+        for (int n = 0; n < S.n_prim; ++n) Q[n] = prim(i, j, k, n);
         visc_coeffs(S, Q, T, mu, kappa);
     };
     Real dudx = 0, dudy = 0, dudz = 0, dvdx = 0, dvdy = 0, dwdx = 0, dwdz = 0, divu = 0;
@@ -2256,10 +2259,8 @@ void* orc_create(const cmfp_geometry* g, const cmfp_params* p, int n_states, con
     for (int s = 0; s < n_states; ++s) setup_state(S->states[s], sd[s], *p);
     S->actions.resize(n_actions);
     for (int a = 0; a < n_actions; ++a) S->actions[a].desc = ad[a];
-    // mixtures are restated for the transport and the plasma5 / Lorentz sources: collisions, the viscous fluxes
-    // and the Dirichlet tables below keep the constants of species 0
-    for (int s = 0; s < n_states; ++s)
-        if (sd[s].kind == CMFP_STATE_HYDRO && sd[s].mixture && sd[s].viscosity) flag_abort();
+    // mixtures are restated for the transport, the viscous fluxes and the plasma5 / Lorentz sources: collisions
+    // keep the constants of species 0
     for (int a = 0; a < n_actions; ++a)
         if (ad[a].kind == CMFP_ACTION_COLLISIONS_RAMBO)
             for (int n = 0; n < ad[a].n_states; ++n)
@@ -2301,7 +2302,6 @@ void orc_destroy(void* h) { delete (Sim*)h; }
 void orc_set_face_values(void* h, int s, int d, int side, int prim, int tng, const double* cell, const double* face) {
     Sim* S = (Sim*)h;
     StateDef& st = S->states[s];
-    if (st.desc.mixture) flag_abort();
     st.tng = tng;
     const Box cb = tab_box(S->G.domain, S->G.DIM, tng, d, side, false), fb = tab_box(S->G.domain, S->G.DIM, tng, d, side, true);
     st.tab[d][side][prim].cell.assign(cell, cell + cb.npts());
