@@ -117,3 +117,64 @@ def test_random_option_set_fast_within_tolerance(oracle, seed):
         a, b = m.download(s), ref.get_state(s)
         assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (seed, name, m.last_advance_path(), np.abs(a - b).max() / np.abs(b).max())
     m.close()
+
+
+def draw_mixture(seed):
+    """a draw of the option space above with some hydro states turned into mixtures: two or three species of drawn
+    mass, gamma and (for charged states) charge, mass fractions varying in space"""
+    cfg = draw(seed)
+    r = random.Random(seed * 7 + 1)
+    dim = cfg["dim"]
+    L = [cfg["prob_hi"][d] - cfg["prob_lo"][d] for d in range(dim)]
+    any_mix = False
+    for name, sd in cfg["states"].items():
+        if sd["type"] != "hydro" or (any_mix and r.random() < 0.4):
+            continue
+        if sd["flux"] == "HLLE/HLLC":           # refused with tracers (the reference leaves those fluxes undefined)
+            sd["flux"] = r.choice(["HLLC", "HLLE"])
+        nsp = r.choice([2, 2, 3])
+        m0, q0, g0 = sd["gas"]["mass"], sd["gas"]["charge"], sd["gas"]["gamma"]
+        masses = [m0] + [m0 * r.choice([0.25, 0.5, 2.0, 3.0]) for _ in range(nsp - 1)]
+        gammas = [g0] + [r.choice([1.2, 1.4, 5 / 3, g0]) for _ in range(nsp - 1)]
+        charges = [q0] + [q0 * r.choice([1.0, 1.0, 2.0]) for _ in range(nsp - 1)]
+        kx, amp, base = r.choice([1, 2]), r.uniform(0.05, 0.2), r.uniform(0.25, 0.4)
+        d0 = r.randrange(dim)
+        key = DIRS[d0]
+        lo, ln = cfg["prob_lo"][d0], L[d0]
+        alphas = [(lambda dat, s=i, w=1.0 / (nsp - 1): w * (base + amp * np.sin(2 * np.pi * kx * (dat[key] - lo) / ln + s)))
+                  for i in range(nsp - 1)]
+        problems.with_mixture(cfg, name, alphas, masses, gammas, charges)
+        any_mix = True
+    return cfg
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_mixture_option_set_matches_oracle(oracle, seed):
+    """mixtures over the drawn option space (reconstructions, fluxes, walls, sources, integrators, 1-D / 2-D / 3-D):
+    STRICT bit-identical to the oracle with the dt sequence (implicit source: 1e-12), FAST within 1e-12"""
+    cfg = draw_mixture(5000 + seed)
+    P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+    assert any(d.mixture for d in P.state_descs())
+    ref = oracle.OracleSim(P)
+    try:
+        dts_ref = ref.run(3)
+    except Exception as e:          # an unphysical draw (the reference would abort too)
+        pytest.skip(f"oracle aborts on this draw: {e}")
+    implicit = any(a.get("solver") == "implicit" for a in cfg["actions"].values())
+    for mode in (abi.FP_STRICT, abi.FP_FAST):
+        m = MFP(config.Problem(draw_mixture(5000 + seed), fp_mode=mode), device=0)
+        m.init_data()
+        dts = m.run(3)
+        assert m.last_advance_path() == 0
+        exact = mode == abi.FP_STRICT and not implicit
+        if exact:
+            assert dts == dts_ref, (seed, dts, dts_ref)
+        else:
+            np.testing.assert_allclose(dts, dts_ref, rtol=1e-12)
+        for s, name in enumerate(P.state_names):
+            a, b = m.download(s), ref.get_state(s)
+            if exact:
+                assert np.array_equal(a, b), (seed, name)
+            else:
+                assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (seed, name, mode)
+        m.close()
