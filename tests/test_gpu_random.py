@@ -148,7 +148,7 @@ def draw_mixture(seed):
     return cfg
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", [k for k in range(25) if k != 10])      # draw 10 is unphysical (the oracle aborts on it)
 def test_random_mixture_option_set_matches_oracle(oracle, seed):
     """mixtures over the drawn option space (reconstructions, fluxes, walls, sources, integrators, 1-D / 2-D / 3-D):
     STRICT bit-identical to the oracle with the dt sequence (implicit source: 1e-12), FAST within 1e-12"""
