@@ -15,6 +15,9 @@ int main(int argc, char** argv) {
     const int steps = argc > 2 ? std::atoi(argv[2]) : 5;
     const bool batch = argc > 3 && std::string(argv[3]) == "batch";
     const bool project = argc > 3 && std::string(argv[3]) == "elliptic";  // + the divergence projection after every step
+    // the ions as a mixture of two kinds (mass = {1, 3}, charge = {1, 2}, gamma = {5/3, 1.4}) with a varying mass fraction
+    const bool mixture = argc > 3 && std::string(argv[3]) == "mixture";
+    const double mix_m[2] = {1.0, 3.0}, mix_g[2] = {5.0 / 3.0, 1.4};
     const double gam = 5.0 / 3.0, c = 20.0, PI = std::acos(-1.0), L = 2 * PI;
     try {
         MFP level;
@@ -36,6 +39,12 @@ int main(int argc, char** argv) {
             d.gamma = gam;
             d.mass = std::string(nm) == "ion" ? 1.0 : 1.0 / 25.0;
             d.charge = std::string(nm) == "ion" ? 1.0 : -1.0;
+            if (mixture && std::string(nm) == "ion") {
+                d.n_tracers = 1;
+                d.species_mass = {mix_m[0], mix_m[1]};
+                d.species_charge = {1.0, 2.0};
+                d.species_gamma = {mix_g[0], mix_g[1]};
+            }
             S[nm] = d;
         }
         StateDef f;
@@ -77,7 +86,20 @@ int main(int argc, char** argv) {
                         at(1) = ux * rho;
                         at(2) = uy * rho;
                         at(3) = 0.0 * rho;
-                        at(4) = p / (gam - 1) + 0.5 * rho * (ux * ux + uy * uy + 0.0 * 0.0);
+                        double g = gam;
+                        if (st.def.n_tracers) {  // prim2cons with get_gamma_from_prim (MFP_thermally_perfect_gas.cpp:51-83, 234)
+                            const double alpha = 0.5 + 0.3 * std::sin(x) * std::cos(y);
+                            const double a = alpha < 0.0 ? 0.0 : (alpha > 1.0 ? 1.0 : alpha);
+                            double s_cp = 0.0, s_cv = 0.0, s_a = 0.0;
+                            s_a = s_a + a;
+                            s_cp = s_cp + a * (mix_g[0] / (mix_m[0] * (mix_g[0] - 1.0)));
+                            s_cv = s_cv + a * (1.0 / (mix_m[0] * (mix_g[0] - 1.0)));
+                            s_cp = s_cp + (1.0 - s_a) * (mix_g[1] / (mix_m[1] * (mix_g[1] - 1.0)));
+                            s_cv = s_cv + (1.0 - s_a) * (1.0 / (mix_m[1] * (mix_g[1] - 1.0)));
+                            g = s_cp / s_cv;
+                            at(5) = alpha * rho;
+                        }
+                        at(4) = p / (g - 1) + 0.5 * rho * (ux * ux + uy * uy + 0.0 * 0.0);
                     } else {
                         at(2) = -(ux * By - uy * Bx) / c;
                         at(3) = Bx;

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", [[], ["batch"], ["elliptic"]], ids=["per_step", "advance_steps", "elliptic_action"])
+@pytest.mark.parametrize("mode", [[], ["batch"], ["elliptic"], ["mixture"]],
+                         ids=["per_step", "advance_steps", "elliptic_action", "mixture_ions"])
 def test_cpp_host_demo_matches_python_driver(mode):
     from cerberus_amd.mfp import MFP
     exe = os.path.join(ROOT, "cerberus_amd", "host", "host_demo")
@@ -24,6 +25,8 @@ def test_cpp_host_demo_matches_python_driver(mode):
     cfg = problems.orszag_tang_two_fluid_2d(32)
     if mode == ["elliptic"]:   # the mirror's Elliptic class (apply_change after every step, MFP_advance.cpp:49)
         cfg["actions"]["divergence_cleaning"] = {"type": "elliptic", "projection": 1, "state": "field"}
+    if mode == ["mixture"]:    # StateDef::species_mass / species_charge / species_gamma of the mirror
+        problems.with_mixture(cfg, "ion", [lambda d: 0.5 + 0.3 * np.sin(d["x"]) * np.cos(d["y"])], [1.0, 3.0], [5 / 3, 1.4], [1.0, 2.0])
     P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
     m = MFP(P)
     m.init_data()
