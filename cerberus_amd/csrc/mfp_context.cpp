@@ -1806,11 +1806,21 @@ int cmfp_elliptic_project(cmfp_context* c, int fs, int n_species, const int* spe
     for (int n = 0; n < n_species; ++n) {
         if (species[n] < 0 || species[n] >= (int)c->states.size() || c->states[species[n]].sp.kind != CMFP_STATE_HYDRO)
             return fail(c, CMFP_ERR_INVALID, "elliptic: species must be hydro states");
-        if (c->states[species[n]].desc.mixture)
-            return fail(c, CMFP_ERR_INVALID, "elliptic: the charge density of a mixture (per-cell charge / mass) is not built");
         q.rho[n] = c->states[species[n]].new_data;                                  // Density component
         q.r[n] = c->states[species[n]].desc.charge / c->states[species[n]].desc.mass;
+        const cmfp_state_desc& sd = c->states[species[n]].desc;
+        if (sd.mixture) {
+            SpeciesMix& M = q.mix[n];
+            for (int i = 0; i <= sd.n_tracers; ++i) {
+                M.m[i] = sd.species_mass[i];
+                M.q[i] = sd.species_charge[i];
+                if (M.m[i] != M.m[0]) M.flags |= 1;
+                if (M.q[i] != M.q[0]) M.flags |= 2;
+            }
+            M.nt = M.flags ? sd.n_tracers : 0;
+        }
     }
+    q.sc = c->g.sc;
     HIPCHK(c, cmfp_ell::setup(c->g, c->ell));
     double* F = c->states[fs].new_data;
     const long sc = c->g.sc;

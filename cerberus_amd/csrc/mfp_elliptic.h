@@ -11,8 +11,10 @@ struct Cplx {
 // S_cc = -cd_scale * (sum_s rho_s q_s / m_s) / ep on the valid cells
 struct ChargeArgs {
     int ns;
-    const double* rho[8];
+    const double* rho[8];  // the species' conserved data (Density first; a mixture's tracers at comps 5 ..)
     double r[8];
+    cmfp::SpeciesMix mix[8];  // nt != 0: charge / mass of a cell from its mass fractions (MFP_hydro.cpp:1720-1721)
+    long sc;                  // component stride of the species' arrays
     const double* ep;
     double cd_scale;
 };

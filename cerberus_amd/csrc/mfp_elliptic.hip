@@ -33,7 +33,28 @@ __global__ void k_ell_charge(Geo g, ChargeArgs a, double* __restrict__ S) {
     const int i = (int)(t % g.n[0]), j = (int)((t / g.n[0]) % g.n[1]), k = (int)(t / ((long)g.n[0] * g.n[1]));
     const long c = g.at(i, j, k);
     double cd = 0.0;
-    for (int s = 0; s < a.ns; ++s) cd += a.rho[s][c] * a.r[s];
+    for (int s = 0; s < a.ns; ++s) {
+        const double rho = a.rho[s][c];
+        double r = a.r[s];
+        const cmfp::SpeciesMix& M = a.mix[s];
+        if (M.nt) {  // get_charge_from_cons / get_mass_from_cons (MFP_hydro_gas.cpp:72-96, 123-150)
+            double S_aq = 0.0, S_am = 0.0, S_a = 0.0;
+            for (int i = 0; i < 2; ++i)
+                if (i < M.nt) {
+                    double al = a.rho[s][c + (5 + i) * a.sc] / rho;
+                    al = (al < 0.0) ? 0.0 : ((1.0 < al) ? 1.0 : al);
+                    S_aq += al * M.q[i] / M.m[i];
+                    S_am += al / M.m[i];
+                    S_a += al;
+                }
+            S_aq += (1.0 - S_a) * M.q[M.nt] / M.m[M.nt];
+            S_am += (1.0 - S_a) / M.m[M.nt];
+            const double m = (M.flags & 1) ? 1.0 / S_am : M.m[0];
+            const double q = (M.flags & 2) ? S_aq / S_am : M.q[0];
+            r = q / m;
+        }
+        cd += rho * r;
+    }
     cd = cd / a.ep[c];
     S[t] = cd * (-a.cd_scale);
 }

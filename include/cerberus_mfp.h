@@ -157,8 +157,8 @@ typedef struct {
      * The plasma5 / Lorentz sources and the plasma dt limit read mass and charge of a cell the same way
      * (get_mass_from_cons / get_charge_from_cons, MFP_plasma5.cpp:199-202,364-365,544-545; species_charge).
      * Built on the stage-by-stage kernels (CTU / RK2 / euler updates, viscous fluxes, Dirichlet faces, sources,
-     * dt limits); a mixture state in a collisions_rambo or elliptic action is refused by cmfp_create /
-     * cmfp_elliptic_project. */
+     * dt limits) and in the charge density of cmfp_elliptic_project; a mixture state in a collisions_rambo action
+     * is refused by cmfp_create. */
     int mixture;
     double species_mass[CMFP_MAX_TRACERS + 1];
     double species_gamma[CMFP_MAX_TRACERS + 1];

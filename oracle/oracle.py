@@ -220,8 +220,14 @@ class OracleSim:
                 raise NotImplementedError("divergence projection: periodic dimensions only")
             r = self.p.ref
             gas = lambda s: self.p.cfg["states"][self.p.state_names[s]]["gas"]
+
+            def r_of(s):     # get_charge_from_cons / get_mass_from_cons (HydroState::calc_current_and_charge, MFP_hydro.cpp:1720-1721)
+                from cerberus_amd import config
+                U = self.get_state(s)
+                al = [U[5 + i] / U[0] for i in range(config.gas_n_tracers(gas(s)))]
+                return config.gas_charge_from_alpha(gas(s), al) / config.gas_mass_from_alpha(gas(s), al)
             F = project_divergence_field(self.get_state(fs), [self.get_state(s)[0] for s in species],
-                                         [float(gas(s)["charge"]) / float(gas(s)["mass"]) for s in species],
+                                         [r_of(s) for s in species],
                                          self.p.dx, self.p.dim, r["Larmor"] / (r["Debye"] ** 2 * r["lightspeed"]))
             self.set_state(fs, F)
 

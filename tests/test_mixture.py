@@ -312,6 +312,54 @@ def test_mixture_plasma_frequency_gpu(mix, mode):
     assert err <= pp.OSC_TOL and back <= pp.OSC_TOL and uniform <= 1e-12, (err, back, uniform)
 
 
+def _cleaned_mixture_ot(n):
+    cfg = problems.orszag_tang_two_fluid_2d(n)
+    cfg["actions"]["divergence_cleaning"] = {"type": "elliptic", "projection": 1, "state": "field"}
+    return problems.with_mixture(cfg, "ion", [lambda d: 0.5 + 0.3 * np.sin(d["x"]) * np.cos(d["y"])], [1.0, 3.0],
+                                 [5 / 3, 1.4], [1.0, 2.0])
+
+
+def test_mixture_charge_density_in_the_projection_oracle(oracle):
+    """the elliptic action's charge density takes charge / mass of a cell from its mass fractions
+    (HydroState::calc_current_and_charge, MFP_hydro.cpp:1720-1721): after the projection div D equals that density"""
+    P = config.Problem(_cleaned_mixture_ot(32))
+    plain = _cleaned_mixture_ot(32)
+    del plain["actions"]["divergence_cleaning"]
+    a, b = oracle.OracleSim(P), oracle.OracleSim(config.Problem(plain))
+    dt = b.est_time_step()
+    a.advance(dt)
+    b.advance(dt)
+    fs, si, se = (P.state_index[k] for k in ("field", "ion", "electron"))
+    I, E = b.get_state(si), b.get_state(se)
+    assert np.array_equal(a.get_state(si), I)                      # the projection leaves the fluids alone
+    al = I[5] / I[0]
+    n_over_rho = al / 1.0 + (1 - al) / 3.0                         # 1 / m of the mixture, written out for two species
+    r_ion = ((al * 1.0 / 1.0 + (1 - al) * 2.0 / 3.0) / n_over_rho) * n_over_rho
+    r = P.ref
+    want = oracle.project_divergence_field(b.get_state(fs), [I[0], E[0]], [r_ion, -1.0 / 0.04], P.dx, P.dim,
+                                           r["Larmor"] / (r["Debye"] ** 2 * r["lightspeed"]))
+    got = a.get_state(fs)
+    assert rel_linf(got, want) <= 1e-13
+    const = oracle.project_divergence_field(b.get_state(fs), [I[0], E[0]], [1.0, -1.0 / 0.04], P.dx, P.dim,
+                                            r["Larmor"] / (r["Debye"] ** 2 * r["lightspeed"]))
+    assert rel_linf(got, const) > 1e-6                             # the charge / mass of species 0 alone is elsewhere
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [abi.FP_STRICT, abi.FP_FAST])
+def test_mixture_with_elliptic_action_gpu(oracle, mode):
+    """two-fluid run with mixture ions and the divergence projection after every step: as for the single-species
+    case held to 1e-11 (the FFT round-off of the projection enters every step)"""
+    P = config.Problem(_cleaned_mixture_ot(64), fp_mode=mode)
+    ref = oracle.OracleSim(config.Problem(_cleaned_mixture_ot(64)))
+    m = _gpu(P)
+    dts_ref, dts = ref.run(5), m.run(5)
+    np.testing.assert_allclose(dts, dts_ref, rtol=1e-12)
+    for s in range(3):
+        assert rel_linf(m.download(s), ref.get_state(s)) <= 1e-11, P.state_names[s]
+    m.close()
+
+
 @pytest.mark.gpu
 def test_mixture_refusals_of_the_library():
     """a mixture in a collisions action or with Dirichlet face data: CMFP_ERR_INVALID, nothing silently approximated"""
