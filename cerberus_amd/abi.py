@@ -26,6 +26,7 @@ VISCOSITY = {"Sutherland": 1, "PowerLaw": 2, "UserDefined": 3}
 TIME_INTEGRATOR = {"euler": 0, "RK2": 1, "strang": 2}
 FP_STRICT, FP_FAST = 0, 1
 STATIC_MAX_STEPS = 4096   # CMFP_STATIC_MAX_STEPS
+IPC_HANDLE_BYTES = 64     # CMFP_IPC_HANDLE_BYTES (sizeof(hipIpcMemHandle_t))
 
 
 class Geometry(C.Structure):

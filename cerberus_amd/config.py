@@ -311,7 +311,7 @@ class Problem:
     def elliptic_actions(self):
         """[(field state index, [species state indices])] of the `elliptic` actions, sorted by name:
         Elliptic::Elliptic (MFP_elliptic.cpp:31-68) and the species of the plasma5 actions associated with the
-        field (:700-712).  Only projection = 1 is built (the static-field solve is outside the path)."""
+        field (:722-755).  Only projection = 1 is built (the static-field solve is outside the path)."""
         out = []
         for name in self.elliptic_names:
             ad = self.cfg["actions"][name]
@@ -322,11 +322,14 @@ class Problem:
                 raise ValueError(f"Action '{name}' requires option 'state' to be defined.")
             if self.cfg["states"][st]["type"] != "field":
                 raise ValueError(f"An invalid state has been defined for the '{name}' action")
+            # project_divergence_field zeroes the charge density inside its loop over the field's associated
+            # actions (`local_cd.setVal(0.0)`, MFP_elliptic.cpp:722-735) and divides by ep per action: with several
+            # plasma5 actions on one field only the last one, in sorted-name order, contributes.  Reproduced.
             species = []
             for an in self.action_names:
                 a = self.cfg["actions"][an]
                 if a["type"] == "plasma5" and st in a["states"]:
-                    species += [self.state_index[n] for n in a["states"] if self.cfg["states"][n]["type"] == "hydro"]
+                    species = [self.state_index[n] for n in a["states"] if self.cfg["states"][n]["type"] == "hydro"]
             out.append((self.state_index[st], species))
         return out
 

@@ -7,6 +7,7 @@
 #include "../../include/cerberus_mfp.h"
 #include "mfp_types.h"
 #include "mfp_elliptic.h"
+#include "mfp_peer.h"
 
 #include <hip/hip_runtime.h>
 
@@ -110,6 +111,20 @@ struct cmfp_context {
     double* d_dtbuf = nullptr;  // cmfp_advance_steps: device-resident dt + dt log
     int d_dtcap = 0;
     cmfp_ell::Work ell;  // divergence projection scratch (cmfp_elliptic_project)
+    // device-side halo / dt transport between ranks (cmfp_peer_*, mfp_peer.h)
+    struct PeerRT {
+        bool enabled = false;
+        int rank = -1, world = 0;
+        char* arena = nullptr;                         // this rank's arena (hipMalloc)
+        char* remote[cmfp_peer::MAX_RANKS] = {};       // every rank's arena as this process sees it; remote[rank] = arena
+        bool opened[cmfp_peer::MAX_RANKS] = {};        // mapped with hipIpcOpenMemHandle: closed by cmfp_destroy
+        int nb[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}}; // neighbour rank of face (d, side), -1: none
+        unsigned long long msg[3] = {0, 0, 0};         // halo messages sent so far, per dimension
+        unsigned long long dtmsg = 0;
+        std::vector<size_t> state_off[3];              // doubles: offset of each state's face inside a slot of dimension d
+        cmfp_peer::Layout L;
+        double timeout_s = 20.0;                       // bound of every device-side wait (CMFP_PEER_TIMEOUT)
+    } peer;
     bool no_alloc = false;  // inside cmfp_advance_steps_static: anything that would allocate fails instead
     unsigned long long* d_red = nullptr;  // one reduction word per state + per action
     double* d_part = nullptr;             // CMFP_RED_BLOCKS block partials per word
@@ -128,7 +143,13 @@ struct cmfp_context {
 namespace {
 
 int fail(cmfp_context* c, int code, const std::string& msg) {
-    if (c) c->err = msg;
+    if (c) {
+        c->err = msg;
+        // cmfp_last_error_cell describes the *last* error: any failure forgets the cell of an earlier
+        // CMFP_ERR_PHYSICS (sync_and_check sets it again after this call where it found one)
+        c->err_state = -1;
+        c->err_cell[0] = c->err_cell[1] = c->err_cell[2] = -1;
+    }
     return code;
 }
 #define HIPCHK(c, call)                                                                              \
@@ -198,6 +219,90 @@ int ensure_staged(cmfp_context* c, StateRT& s) {
     return CMFP_OK;
 }
 
+// ---- device-side transport between ranks (mfp_peer.h) -------------------------------------------------------
+long long halo_doubles(const cmfp_context* c, int s, int dim) {
+    long long n = (long long)c->states[s].sp.nc * c->states[s].fill_ng;
+    for (int t = 0; t < 3; ++t)
+        if (t != dim) n *= c->g.ext[t];
+    return n;
+}
+// arena layout: identical on every rank (same block shape, same states, same ghost widths)
+void peer_layout(cmfp_context* c) {
+    auto& P = c->peer;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    P.L.ready = take(sizeof(unsigned long long) * 6);
+    P.L.dtready = take(sizeof(unsigned long long) * cmfp_peer::MAX_RANKS);
+    P.L.dtslot = take(sizeof(double) * 2 * cmfp_peer::MAX_RANKS);
+    for (int d = 0; d < 3; ++d) {
+        P.state_off[d].assign(c->states.size(), 0);
+        size_t n = 0;
+        if (d < c->g.dim && c->split[d])
+            for (size_t q = 0; q < c->states.size(); ++q) {
+                P.state_off[d][q] = n;
+                n += (size_t)halo_doubles(c, (int)q, d);
+            }
+        for (int side = 0; side < 2; ++side)
+            for (int par = 0; par < 2; ++par) P.L.recv[d][side][par] = take(sizeof(double) * n);
+    }
+    P.L.bytes = off;
+}
+// the ghost layers of `list` across the split dimension d: what the exchange callback does, without the host
+int peer_exchange(cmfp_context* c, const int* list, int nlist, int d) {
+    auto& P = c->peer;
+    const unsigned long long m = ++P.msg[d];
+    const int par = (int)(m & 1ull);
+    cmfp_peer::Flags2 sig, wt;
+    sig.n = wt.n = 0;
+    sig.value = wt.value = m;
+    for (int side = 0; side < 2; ++side) {
+        const int nb = P.nb[d][side];
+        if (nb < 0) continue;
+        // my face `side` is the neighbour's ghost region on its opposite side
+        double* slot = reinterpret_cast<double*>(P.remote[nb] + P.L.recv[d][1 - side][par]);
+        for (int k = 0; k < nlist; ++k) {
+            const StateRT& st = c->states[list[k]];
+            cmfp_peer::pack(c->g, st.sp.nc, st.fill_ng, st.new_data, d, side, slot + P.state_off[d][list[k]], c->stream);
+        }
+        sig.flag[sig.n++] = reinterpret_cast<unsigned long long*>(P.remote[nb] + P.L.ready) + (2 * d + (1 - side));
+        wt.flag[wt.n++] = reinterpret_cast<unsigned long long*>(P.arena + P.L.ready) + (2 * d + side);
+    }
+    cmfp_peer::signal(sig, c->stream);
+    cmfp_peer::wait(wt, c->d_err + 1, P.timeout_s, c->stream);
+    for (int side = 0; side < 2; ++side) {
+        if (P.nb[d][side] < 0) continue;
+        const double* slot = reinterpret_cast<const double*>(P.arena + P.L.recv[d][side][par]);
+        for (int k = 0; k < nlist; ++k) {
+            StateRT& st = c->states[list[k]];
+            cmfp_peer::unpack(c->g, st.sp.nc, st.fill_ng, st.new_data, d, side, slot + P.state_off[d][list[k]], c->stream);
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, CMFP_ERR_HIP, std::string("peer exchange launch: ") + hipGetErrorString(e));
+    return CMFP_OK;
+}
+// ParallelDescriptor::ReduceRealMin of the device-resident dt (MFP_timestep.cpp:18)
+int peer_dt_min(cmfp_context* c, double* d_dt) {
+    auto& P = c->peer;
+    cmfp_peer::DtPeers a;
+    std::memset(&a, 0, sizeof(a));
+    a.rank = P.rank;
+    a.world = P.world;
+    for (int r = 0; r < P.world; ++r) a.arena[r] = P.remote[r];
+    a.dtready = P.L.dtready;
+    a.dtslot = P.L.dtslot;
+    a.value = ++P.dtmsg;
+    cmfp_peer::dt_put(a, d_dt, c->stream);
+    cmfp_peer::dt_min(a, d_dt, c->d_err + 1, P.timeout_s, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, CMFP_ERR_HIP, std::string("peer dt minimum launch: ") + hipGetErrorString(e));
+    return CMFP_OK;
+}
+
 FillRules bc_rules(const StateRT& s, int d, int side) {
     FillRules r;
     for (int n = 0; n < 10; ++n) {
@@ -234,6 +339,11 @@ int fill_patch(cmfp_context* c, int si) {
             for (int side = 0; side < 2; ++side)
                 if (c->touches[d][side])
                     c->L->fill_dim(g, s.sp.nc, s.fill_ng, s.new_data, d, side, bc_rules(s, d, side), c->stream);
+            if (c->peer.enabled) {
+                int r = peer_exchange(c, &si, 1, d);
+                if (r) return r;
+                continue;
+            }
             if (!c->exchange)
                 return fail(c, CMFP_ERR_INVALID, "domain is split along a dimension but no exchange callback is set");
             int r = c->exchange(c->exchange_user, c, si, d);
@@ -274,6 +384,11 @@ int fill_patch_many(cmfp_context* c, const std::vector<int>& list, int skip_dims
         }
         flush();
         if (!c->split[d]) continue;
+        if (c->peer.enabled) {  // device-side transport: one message per neighbour carries the listed states
+            int r = peer_exchange(c, list.data(), (int)list.size(), d);
+            if (r) return r;
+            continue;
+        }
         if (!c->exchange) return fail(c, CMFP_ERR_INVALID, "domain is split along a dimension but no exchange callback is set");
         if (c->exchange_batched) {
             if (c->exchange(c->exchange_user, c, CMFP_ALL_STATES, d)) return fail(c, CMFP_ERR_INVALID, "exchange callback failed");
@@ -1144,16 +1259,24 @@ int check_ctx(cmfp_context* c) {
 }
 
 int sync_and_check(cmfp_context* c) {
-    int h_err = 0;
-    HIPCHK(c, hipMemcpyAsync(&h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    int h_err2[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(h_err2, c->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_err2[1]) {
+        // a bounded wait of the device-side transport expired: a neighbour's message (or dt word) never arrived.
+        // Whatever was computed since is meaningless; the words are cleared so that the context can be torn down.
+        (void)hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), c->stream);
+        return fail(c, CMFP_ERR_HIP, "peer transport: a device-side wait for a neighbour rank timed out (" +
+                                         std::to_string(c->peer.timeout_s) + " s); results since the last check are invalid");
+    }
+    const int h_err = h_err2[0];
     if (!h_err) return CMFP_OK;
     // Post-mortem: the first cell (state order, then memory order) whose cell-centred values are invalid now.  The
     // kernels flag invalid *face* states too (after reconstruction or a transverse correction); those leave no
     // invalid cell behind and are reported without a location.
     std::string where = " (no cell-centred value is invalid: a face state failed after reconstruction or transverse correction)";
-    c->err_state = -1;
-    for (size_t s = 0; s < c->states.size() && c->err_state < 0; ++s) {
+    int bad_state = -1, bad_cell[3] = {-1, -1, -1};
+    for (size_t s = 0; s < c->states.size() && bad_state < 0; ++s) {
         if (c->states[s].sp.kind != CMFP_STATE_HYDRO) continue;
         unsigned long long h = ~0ull;
         if (hipMemsetAsync(c->d_errcell, 0xff, sizeof(h), c->stream) != hipSuccess) break;
@@ -1161,15 +1284,18 @@ int sync_and_check(cmfp_context* c) {
         if (hipMemcpyAsync(&h, c->d_errcell, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess) break;
         if (hipStreamSynchronize(c->stream) != hipSuccess) break;
         if (h == ~0ull) continue;
-        c->err_state = (int)s;
-        c->err_cell[0] = (int)(h % (unsigned long long)c->g.n[0]);
-        c->err_cell[1] = (int)((h / (unsigned long long)c->g.n[0]) % (unsigned long long)c->g.n[1]);
-        c->err_cell[2] = (int)(h / ((unsigned long long)c->g.n[0] * (unsigned long long)c->g.n[1]));
-        where = " first offending cell: state " + std::to_string(s) + ", cell (" + std::to_string(c->err_cell[0]) + ", " +
-                std::to_string(c->err_cell[1]) + ", " + std::to_string(c->err_cell[2]) + ") of this block";
+        bad_state = (int)s;
+        bad_cell[0] = (int)(h % (unsigned long long)c->g.n[0]);
+        bad_cell[1] = (int)((h / (unsigned long long)c->g.n[0]) % (unsigned long long)c->g.n[1]);
+        bad_cell[2] = (int)(h / ((unsigned long long)c->g.n[0] * (unsigned long long)c->g.n[1]));
+        where = " first offending cell: state " + std::to_string(s) + ", cell (" + std::to_string(bad_cell[0]) + ", " +
+                std::to_string(bad_cell[1]) + ", " + std::to_string(bad_cell[2]) + ") of this block";
     }
     (void)hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream);  // the flag is per failure, not sticky
-    return fail(c, CMFP_ERR_PHYSICS, "Primitive values outside of physical bounds!!" + where);
+    const int rc = fail(c, CMFP_ERR_PHYSICS, "Primitive values outside of physical bounds!!" + where);
+    c->err_state = bad_state;
+    for (int d = 0; d < 3; ++d) c->err_cell[d] = bad_cell[d];
+    return rc;
 }
 
 }  // namespace
@@ -1330,9 +1456,9 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
                     StateRT& st = c->states[A.states[i]];
                     st.fill_ng = std::max(st.fill_ng, c->states[A.states[2]].sp.ng);
                 }
-    HIPCHK(c, hipMalloc((void**)&c->d_err, sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->d_err, 2 * sizeof(int)));  // [0]: invalid primitives, [1]: a device-side wait of the peer transport gave up
     HIPCHK(c, hipMalloc((void**)&c->d_errcell, sizeof(unsigned long long)));
-    HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), c->stream));
     HIPCHK(c, hipMalloc((void**)&c->d_flag, sizeof(int)));
     HIPCHK(c, hipMalloc((void**)&c->d_red, sizeof(unsigned long long) * (2 * n_states + n_actions + 1)));
     HIPCHK(c, hipMalloc((void**)&c->d_part, sizeof(double) * (size_t)(2 * n_states + n_actions + 1) * CMFP_RED_BLOCKS));
@@ -1369,6 +1495,9 @@ int cmfp_destroy(cmfp_context* c) {
         (void)hipEventDestroy(c->ev_int);
         if (c->ev_hyd) (void)hipEventDestroy(c->ev_hyd);
     }
+    for (int r = 0; r < cmfp_peer::MAX_RANKS; ++r)
+        if (c->peer.opened[r] && c->peer.remote[r]) (void)hipIpcCloseMemHandle(c->peer.remote[r]);
+    if (c->peer.arena) (void)hipFree(c->peer.arena);
     for (double* p : c->allocs) (void)hipFree(p);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_errcell) (void)hipFree(c->d_errcell);
@@ -1694,7 +1823,9 @@ static int advance_steps_on(cmfp_context* c, double dt0, int nsteps, double* dts
             c->L->new_dt(plan, c->d_red, d_dt, d_log, i, c->stream);
         c->fold_pending = false;
         done = i + 1;
-        if (split_any && c->dt_reduce(c->dt_reduce_user, c, d_dt)) {
+        if (split_any && c->peer.enabled) {
+            if ((rc = peer_dt_min(c, d_dt))) break;
+        } else if (split_any && c->dt_reduce(c->dt_reduce_user, c, d_dt)) {
             rc = fail(c, CMFP_ERR_INVALID, "dt reduce callback failed");
             break;
         }
@@ -1718,7 +1849,7 @@ static int advance_steps_applicable(cmfp_context* c, int nsteps, double* dts, do
     if (!c->fused) return 1;
     bool split_any = false;
     for (int d = 0; d < c->g.dim; ++d) split_any = split_any || c->split[d];
-    if (split_any && !c->dt_reduce) return 1;  // the cross-rank dt minimum needs a callback, else the per-step API
+    if (split_any && !c->dt_reduce && !c->peer.enabled) return 1;  // the cross-rank dt minimum needs the peer transport or a callback, else the per-step API
     return CMFP_OK;
 }
 
@@ -1921,6 +2052,83 @@ int cmfp_set_exchange_batched(cmfp_context* c, int on) {
     c->exchange_batched = on != 0;
     return CMFP_OK;
 }
+
+// ---- device-side transport between ranks (include/cerberus_mfp.h, mfp_peer.h)
+int cmfp_peer_init(cmfp_context* c, int rank, int world, void* ipc_handle_out, void** arena_out) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (world < 1 || world > cmfp_peer::MAX_RANKS || rank < 0 || rank >= world)
+        return fail(c, CMFP_ERR_INVALID, "cmfp_peer_init: rank / world out of range (at most " + std::to_string(cmfp_peer::MAX_RANKS) + " ranks)");
+    if (c->peer.arena) return fail(c, CMFP_ERR_INVALID, "cmfp_peer_init: already initialised");
+    static_assert(sizeof(hipIpcMemHandle_t) == CMFP_IPC_HANDLE_BYTES, "CMFP_IPC_HANDLE_BYTES");
+    auto& P = c->peer;
+    P.rank = rank;
+    P.world = world;
+    if (const char* e = std::getenv("CMFP_PEER_TIMEOUT")) P.timeout_s = std::max(0.05, std::atof(e));
+    peer_layout(c);
+    HIPCHK(c, hipMalloc((void**)&P.arena, P.L.bytes));
+    HIPCHK(c, hipMemsetAsync(P.arena, 0, P.L.bytes, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the words are zero before any neighbour can learn the address
+    P.remote[rank] = P.arena;
+    if (ipc_handle_out) {
+        hipIpcMemHandle_t h;
+        HIPCHK(c, hipIpcGetMemHandle(&h, P.arena));
+        std::memcpy(ipc_handle_out, &h, sizeof(h));
+    }
+    if (arena_out) *arena_out = P.arena;
+    return CMFP_OK;
+}
+int cmfp_peer_open(cmfp_context* c, int peer_rank, const void* ipc_handle, void* same_process_arena) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    auto& P = c->peer;
+    if (!P.arena) return fail(c, CMFP_ERR_INVALID, "cmfp_peer_open: call cmfp_peer_init first");
+    if (peer_rank < 0 || peer_rank >= P.world || peer_rank == P.rank) return fail(c, CMFP_ERR_INVALID, "cmfp_peer_open: bad peer rank");
+    if (P.remote[peer_rank]) return fail(c, CMFP_ERR_INVALID, "cmfp_peer_open: peer already attached");
+    if (same_process_arena) {
+        // a context of this process: its arena pointer is valid here (the caller has enabled peer access where
+        // the two contexts sit on different devices)
+        P.remote[peer_rank] = static_cast<char*>(same_process_arena);
+        return CMFP_OK;
+    }
+    if (!ipc_handle) return fail(c, CMFP_ERR_INVALID, "cmfp_peer_open: no handle");
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, ipc_handle, sizeof(h));
+    void* p = nullptr;
+    HIPCHK(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    P.remote[peer_rank] = static_cast<char*>(p);
+    P.opened[peer_rank] = true;
+    return CMFP_OK;
+}
+int cmfp_peer_set_neighbour(cmfp_context* c, int dim, int side, int rank) {
+    if (!c) return CMFP_ERR_INVALID;
+    if (dim < 0 || dim >= c->g.dim || side < 0 || side > 1 || rank < -1 || rank >= c->peer.world)
+        return fail(c, CMFP_ERR_INVALID, "cmfp_peer_set_neighbour: bad face or rank");
+    c->peer.nb[dim][side] = rank;
+    return CMFP_OK;
+}
+int cmfp_peer_enable(cmfp_context* c, int on) {
+    if (!c) return CMFP_ERR_INVALID;
+    auto& P = c->peer;
+    if (!on) {
+        P.enabled = false;
+        return CMFP_OK;
+    }
+    if (!P.arena) return fail(c, CMFP_ERR_INVALID, "cmfp_peer_enable: call cmfp_peer_init first");
+    for (int r = 0; r < P.world; ++r)
+        if (!P.remote[r]) return fail(c, CMFP_ERR_INVALID, "cmfp_peer_enable: rank " + std::to_string(r) + " is not attached (the dt minimum writes to every rank)");
+    for (int d = 0; d < c->g.dim; ++d)
+        for (int side = 0; side < 2; ++side) {
+            const bool needs = c->split[d] && !c->touches[d][side];
+            if (needs && P.nb[d][side] < 0)
+                return fail(c, CMFP_ERR_INVALID, "cmfp_peer_enable: face (" + std::to_string(d) + ", " + std::to_string(side) + ") has no neighbour rank");
+            if (!needs && P.nb[d][side] >= 0)
+                return fail(c, CMFP_ERR_INVALID, "cmfp_peer_enable: a neighbour is set on a face that is not an inter-rank face");
+        }
+    P.enabled = true;
+    return CMFP_OK;
+}
+int cmfp_peer_enabled(const cmfp_context* c) { return c && c->peer.enabled ? 1 : 0; }
 
 int cmfp_fill_patch(cmfp_context* c, int s) {
     int r;

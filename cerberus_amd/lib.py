@@ -57,6 +57,11 @@ SYMBOLS = [
     ("cmfp_halo_count", C.c_longlong, [C.c_void_p, C.c_int, C.c_int]),
     ("cmfp_halo_pack", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("cmfp_halo_unpack", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("cmfp_peer_init", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("cmfp_peer_open", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ("cmfp_peer_set_neighbour", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    ("cmfp_peer_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("cmfp_peer_enabled", C.c_int, [C.c_void_p]),
     ("cmfp_leaf_reconstruct", C.c_int, [C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
     ("cmfp_leaf_riemann", C.c_int, [C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,

@@ -41,7 +41,11 @@ def coords_rank(c, grid):
 
 class MFP:
     def __init__(self, problem, device=0, rank=0, world=1, stream=0, fused=True, pg=None, exchange_device=None,
-                 batched_exchange=True, overlap=1, device_dt=True):
+                 batched_exchange=True, overlap=1, device_dt=True, transport="callback"):
+        """transport (world > 1): "callback" = halos and the dt word through torch.distributed from the
+        exchange / dt-reduce callbacks (RCCL device buffers, or gloo with host staging where exchange_device is
+        "cpu"); "peer" = the library's device-side transport (cmfp_peer_*: neighbours write into each other's
+        IPC-mapped arenas, no host code per step); torch.distributed then only carries the set-up (the handles)."""
         self.L = lib.load()
         self.p = problem if isinstance(problem, Problem) else Problem(problem)
         p = self.p
@@ -86,7 +90,10 @@ class MFP:
         self._cb = None
         self._bufs = {}
         self._exchange_device = exchange_device
-        if world > 1:
+        self.transport = transport if world > 1 else "none"
+        if world > 1 and transport == "peer":
+            self._peer_setup()
+        elif world > 1:
             self._cb = lib.EXCHANGE_FN(self._exchange)
             self._chk(self.L.cmfp_set_exchange_callback(self.h, self._cb, None))
             self._chk(self.L.cmfp_set_exchange_batched(self.h, int(batched_exchange)))
@@ -279,6 +286,26 @@ class MFP:
 
     def fill_patch(self, s):
         self._chk(self.L.cmfp_fill_patch(self.h, s))
+
+    # -- device-side transport (cmfp_peer_*) ---------------------------------
+    def _peer_setup(self):
+        """every rank allocates its arena, the IPC handles are all-gathered (set-up only), every rank maps every
+        other rank's arena and names its face neighbours; after a barrier the library moves halos and the dt
+        word itself"""
+        import torch.distributed as dist
+        handle = C.create_string_buffer(abi.IPC_HANDLE_BYTES)
+        self._chk(self.L.cmfp_peer_init(self.h, self.rank, self.world, handle, None))
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle.raw), group=self.pg)
+        for r in range(self.world):
+            if r != self.rank:
+                self._chk(self.L.cmfp_peer_open(self.h, r, C.create_string_buffer(handles[r], abi.IPC_HANDLE_BYTES), None))
+        for d in range(self.p.dim):
+            for side in (0, 1):
+                nb = self.neighbour(d, side) if self.grid[d] > 1 else None
+                self._chk(self.L.cmfp_peer_set_neighbour(self.h, d, side, -1 if nb is None else nb))
+        dist.barrier(group=self.pg)      # every arena is zeroed and mapped before the first message
+        self._chk(self.L.cmfp_peer_enable(self.h, 1))
 
     # -- halo exchange between ranks ----------------------------------------
     def _comm_device(self):

@@ -303,8 +303,9 @@ int cmfp_advance_steps_static(cmfp_context* ctx, double time, double dt0, int ns
 /* Elliptic::apply_change with projection = 1 (actions/MFP_elliptic.cpp:70-81): project_divergence_field
  * (:667-782) = two calls of solve_divergence (:784-964) on the new-time data of `field_state` - the B field
  * with psi, then the D field with phi and the cell-centred source -Larmor / (Debye^2 c) * rho_c / ep, rho_c
- * the charge density of the n_species hydro states listed (the species of the plasma5 actions associated with
- * the field, :700-765).  The host side calls it after cmfp_advance for every `elliptic` action, where the
+ * the charge density of the n_species hydro states listed (the species of the LAST plasma5 action, in sorted-name
+ * order, associated with the field: the reference zeroes its charge density inside the loop over the associated
+ * actions, :722-766, so earlier plasma5 actions on the same field do not contribute).  The host side calls it after cmfp_advance for every `elliptic` action, where the
  * reference's MFP::advance loops apply_change (MFP_advance.cpp:49).  The reference solves with AMReX's nodal
  * projection (MLNodeLaplacian + MLMG, third party, absent from its tree); here the same nodal operators are
  * solved exactly by FFT on periodic blocks: every dimension periodic, a power of two of cells (<= 4096) per
@@ -399,6 +400,31 @@ long long cmfp_halo_count(const cmfp_context* ctx, int state, int dim);
  * ghost layers, side 1 the high ghost layers.  dbuf is device memory. */
 int cmfp_halo_pack(cmfp_context* ctx, int state, int dim, int side, double* dbuf);
 int cmfp_halo_unpack(cmfp_context* ctx, int state, int dim, int side, const double* dbuf);
+
+/* ---- Device-side transport between ranks: the FillPatch exchange (MFP_action.cpp:59) and the ReduceRealMin of
+ * MFP::estTimeStep (MFP_timestep.cpp:18) without the host on the per-step path.  Every rank owns an arena of
+ * device memory (receive slots for each inter-rank face, progress words, dt slots) that the other ranks map -
+ * across processes with HIP IPC (one process per GPU over xGMI, or several processes sharing one GPU), inside one
+ * process with the plain device pointer - and write into directly: pack kernel into the neighbour's slot, a
+ * system-scope release of its progress word, a bounded device-side wait on the receiver, unpack; the dt minimum
+ * likewise (every rank writes its word into every other rank's slot).  With the transport enabled the exchange
+ * callback and the dt-reduce callback are no longer called and cmfp_advance_steps runs on split blocks.
+ *   1. cmfp_peer_init on every rank: allocates and zeroes the arena, returns its IPC handle
+ *      (CMFP_IPC_HANDLE_BYTES bytes = hipIpcMemHandle_t) and, for same-process use, its device address;
+ *   2. the caller all-gathers the handles (MPI_Allgather / torch.distributed: set-up only);
+ *   3. cmfp_peer_open for EVERY other rank (halos go to neighbours, the dt word to all), cmfp_peer_set_neighbour
+ *      for every inter-rank face (periodic wrap included; -1 on physical faces);
+ *   4. a barrier of the caller (every rank has zeroed and mapped), then cmfp_peer_enable(ctx, 1).
+ * All ranks must make the same sequence of calls afterwards (they do: the step is SPMD).  A wait that sees no
+ * partner for CMFP_PEER_TIMEOUT seconds (environment, default 20) gives up: the kernels still run to completion and
+ * the next synchronising call returns CMFP_ERR_HIP.  At most 64 ranks. */
+#define CMFP_IPC_HANDLE_BYTES 64
+int cmfp_peer_init(cmfp_context* ctx, int rank, int world, void* ipc_handle_out /* [CMFP_IPC_HANDLE_BYTES] or NULL */,
+                   void** arena_out /* or NULL */);
+int cmfp_peer_open(cmfp_context* ctx, int peer_rank, const void* ipc_handle, void* same_process_arena);
+int cmfp_peer_set_neighbour(cmfp_context* ctx, int dim, int side, int rank);
+int cmfp_peer_enable(cmfp_context* ctx, int on);
+int cmfp_peer_enabled(const cmfp_context* ctx);
 
 /* ---- Leaf numerics on device, batched over n independent inputs (SoA:
  * component c of item i at [c*n + i]); device pointers.  They run the very

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, which, batched, ret):
+def _worker(rank, world, port, which, batched, ret, transport="callback"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -26,11 +26,12 @@ def _worker(rank, world, port, which, batched, ret):
     try:
         torch.cuda.set_device(0)
         P = config.Problem(_cfg(which), fp_mode=_mode(which))
-        m = MFP(P, device=0, rank=rank, world=world, exchange_device="cpu", batched_exchange=batched)
+        m = MFP(P, device=0, rank=rank, world=world, exchange_device="cpu", batched_exchange=batched, transport=transport)
         m.init_data()
         dts = m.run(5)
         out = {"dts": dts, "lo": m.block_lo, "n": m.block_n, "fused": m.last_advance_fused(), "device_dt": m._device_dt,
-               "fusion": m.last_source_fusion(), "data": [m.download(s) for s in range(m.n_states)]}
+               "fusion": m.last_source_fusion(), "data": [m.download(s) for s in range(m.n_states)],
+               "peer": bool(m.L.cmfp_peer_enabled(m.h)), "host_t": m.host_times()}
         ret[rank] = out
         m.close()
     finally:
@@ -99,13 +100,30 @@ def _free_port():
                                                  (4, "mix2d", True), (2, "mixot", False), (4, "mixot@fast", True)] +
                                                 [(2 + 2 * (k % 2), f"rand{k}", k % 3 != 0) for k in range(10)])
 def test_decomposed_run_equals_single_rank(world, which, batched):
+    _decomposed(world, which, batched, "callback")
+
+
+# The library's device-side transport (cmfp_peer_*: every rank's arena mapped by the others through HIP IPC, pack
+# kernels write into the neighbour's slot, progress words instead of messages, the dt minimum the same way): the
+# ranks share the one GPU of the box here, on the 8-GPU node the same code runs over xGMI.  Same bar as the
+# callback transport - bit-identical to the single-rank run - and the hooks never run (no host time in them).
+@pytest.mark.parametrize("world,which,batched", [(2, "ot", True), (4, "ot", True), (4, "ot", False), (4, "gem", True), (2, "ot96", False),
+                                                 (4, "ot512", True), (8, "ot512", True), (8, "gem64", True),
+                                                 (4, "rmi3d", True), (8, "rmi3d24", True), (4, "inflow", True),
+                                                 (4, "ot512@fast", True), (8, "ot512@fast", True), (8, "gem64@fast", True),
+                                                 (4, "rmi3d24@fast", True), (4, "mix2d", True), (4, "rand1", True), (2, "rand4", False)])
+def test_decomposed_run_on_the_peer_transport(world, which, batched):
+    _decomposed(world, which, batched, "peer")
+
+
+def _decomposed(world, which, batched, transport):
     import torch.multiprocessing as mp
     from cerberus_amd import abi, config, problems
     from cerberus_amd.mfp import MFP
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, which, batched, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, which, batched, ret, transport)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -132,6 +150,9 @@ def test_decomposed_run_equals_single_rank(world, which, batched):
         else:
             assert o["dts"] == dts
         assert o["fusion"] == fusion
+        assert o["peer"] == (transport == "peer")
+        if transport == "peer":
+            assert o["host_t"] == {"exchange": 0.0, "dt_reduce": 0.0}, "the hooks must not run with the device-side transport"
         if not which.startswith(("rand", "mix")):
             assert o["fused"]           # (since round 2 also the inflow case: marching kernel with the face tables)
             assert o["device_dt"]     # cmfp_advance_steps with the cross-rank dt minimum on the device

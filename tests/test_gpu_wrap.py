@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _gpu(problem, wrap=True, **kw):
+    """wrap: True / False = wrap where it applies / never; 2 / 4 = the bit form of CMFP_MARCH_WRAP: x only / y only"""
     from cerberus_amd.mfp import MFP
     old = os.environ.get("CMFP_MARCH_WRAP")
-    os.environ["CMFP_MARCH_WRAP"] = "1" if wrap else "0"   # read by cmfp_create
+    os.environ["CMFP_MARCH_WRAP"] = str(int(wrap))   # read by cmfp_create
     try:
         m = MFP(problem, **kw)
     finally:
@@ -64,6 +65,36 @@ def test_wrapped_step_equals_filled_step(oracle, name, make, dims, overlap, mode
         assert ref.run(6) == da
         for s in range(a.n_states):
             assert np.array_equal(a.download(s), ref.get_state(s)), (name, P.state_names[s])
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("mode", [abi.FP_STRICT, abi.FP_FAST], ids=["strict", "fast"])
+@pytest.mark.parametrize("wrap,dims", [(4, 2), (2, 1)], ids=["y_only", "x_only"])
+@pytest.mark.parametrize("name", ["ot", "kh"])
+def test_one_direction_wrapped_the_other_filled(oracle, name, wrap, dims, mode):
+    """What a 4096^2 step does (x ghost-fill launch + y wrapped in the kernels, the source prologue on top in FAST:
+    mfp_context.cpp `wrap_flag`), at a size the oracle reaches: STRICT bit-identical to the oracle, FAST within the
+    north-star bound per conserved component, both bit-identical to the step with both fills."""
+    from helpers import rel_linf
+    make = dict((c[0], c[1]) for c in CASES)[name]
+    P = config.Problem(make(), fp_mode=mode)
+    a, b = _gpu(P, wrap=wrap), _gpu(P, wrap=False)
+    da, db = a.run(6), b.run(6)
+    assert a.last_advance_path() == 1 and a.last_wrapped_dims() == dims and b.last_wrapped_dims() == 0
+    if name == "ot" and mode == abi.FP_FAST:
+        assert a.last_source_fusion() == 3
+    assert da == db
+    ref = oracle.OracleSim(P, max_grid_size=32)
+    dr = ref.run(6)
+    for s in range(a.n_states):
+        ua = a.download(s)
+        assert np.array_equal(ua, b.download(s)), (name, P.state_names[s])
+        if mode == abi.FP_STRICT:
+            assert da == dr and np.array_equal(ua, ref.get_state(s)), (name, P.state_names[s])
+        else:
+            np.testing.assert_allclose(da, dr, rtol=1e-12)
+            assert rel_linf(ua, ref.get_state(s)) <= 1e-12, (name, P.state_names[s], rel_linf(ua, ref.get_state(s)))
     a.close()
     b.close()
 
