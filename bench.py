@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--rehearse-fallback", action="store_true",
                     help="diagnostic, with --rehearse: route halos, dt and barriers through a second gloo group, as the fallback "
                          "from a failed RCCL pre-flight does")
+    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "gloo"],
+                    help="N > 1: halo / dt transport; auto = the library's device-side transport (IPC), else RCCL from the "
+                         "callbacks, else host-staged gloo, each after a pre-flight all ranks agree on")
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2],
                     help="diagnostic: cmfp_set_overlap mode (2 = interior / frame split launches even on an unsplit block)")
     ap.add_argument("--no-corner-transport", action="store_true", help="diagnostic: corner_transport=false (not the headline workload)")
@@ -176,63 +179,81 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     ranks_seen = 1
-    staged_pg = None          # set: halos and the dt word travel through host buffers over this gloo group
+    kind = "none"             # transport of halos and the dt word: "peer" | "rccl" | "gloo" | "none" (one rank)
     transport = "none (one rank)"
+    halo_pg = None            # the group the exchange hooks use ("rccl": the RCCL sub-group; else the default gloo group)
     if world > 1:
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        nccl_up = False
-        if not args.rehearse:
+        # gloo first, on every rank: it always comes up, and it carries the control traffic of this script
+        # (barriers, the maximum over ranks of the timed blocks, agreement on the transport, the IPC handles)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+
+        def agree(ok):
+            """every rank takes the same branch: the minimum of the ranks' verdicts, over gloo"""
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        want = args.transport
+        if args.rehearse_fallback:
+            want = "gloo"
+        # 1. the library's device-side transport (cmfp_peer_*): arenas mapped through HIP IPC, no host code per
+        #    step.  Pre-flight: three steps of a small two-fluid problem, decomposed like the run itself; any
+        #    failure on any rank (IPC refused, a device-side wait that times out) selects the next transport.
+        if want in ("auto", "peer"):
+            ok = True
             try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
-                                        timeout=datetime.timedelta(seconds=600))
-                nccl_up = True
-            except Exception as e:       # noqa: BLE001 - the communicator is created eagerly, by all ranks together
-                print(f"[bench rank {rank}] RCCL initialisation failed: {e!r}", file=sys.stderr, flush=True)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-        if not nccl_up:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
-            transport = ("gloo, host-staged (rehearsal on one GPU)" if args.rehearse
-                         else "gloo, host-staged (RCCL initialisation failed)")
-            if args.rehearse_fallback or not args.rehearse:
-                # the plumbing of the fallback below (a second group that carries everything)
-                staged_pg = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
-        else:
-            transport = "RCCL, device buffers"
-            # Pre-flight of exactly what the exchange hooks do (cerberus_amd/mfp.py): a grouped isend / irecv of
-            # device buffers with both ring neighbours and an all-reduce(MIN) of a device double.  The RCCL path
-            # cannot run with more than one rank on the one-GPU boxes this was built on, so if any rank fails here
-            # every rank falls back to host-staged buffers over gloo: a slower transport, still a valid measurement.
-            gloo = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
-            ok = 1
+                P0 = build_problem("ot2f_2d", 64, block_grid(2, world), abi.FP_FAST)
+                m0 = MFP(P0, device=local, rank=rank, world=world, stream=0, exchange_device="cpu", transport="peer")
+                m0.init_data()
+                m0.run(3)
+                import numpy as np
+                ok = all(bool(np.isfinite(m0.download(s)).all()) for s in range(m0.n_states))
+                m0.close()
+            except Exception as e:       # noqa: BLE001 - any failure of this transport selects the next one
+                print(f"[bench rank {rank}] device-side (IPC) transport pre-flight failed: {e!r}", file=sys.stderr, flush=True)
+                ok = False
+            if agree(ok):
+                kind, transport = "peer", "device-side: IPC-mapped arenas, pack kernels write into the neighbour's slot (cmfp_peer_*)"
+                if args.rehearse:
+                    transport += " [rehearsal: all ranks on one GPU]"
+        # 2. torch.distributed on RCCL with device buffers, from the exchange / dt-reduce callbacks (not with
+        #    several ranks on one device: RCCL refuses that).  Pre-flight of exactly the calls the hooks make.
+        if kind == "none" and want in ("auto", "rccl") and not args.rehearse:
+            ok = True
             try:
+                halo_pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=600))
                 snd = torch.full((1024,), float(rank), dtype=torch.float64, device="cuda")
                 rcv = [torch.empty_like(snd), torch.empty_like(snd)]
                 lo, hi = (rank - 1) % world, (rank + 1) % world
                 if lo == hi:
-                    ops = [dist.P2POp(dist.isend, snd, lo), dist.P2POp(dist.isend, snd, hi),
-                           dist.P2POp(dist.irecv, rcv[1], hi), dist.P2POp(dist.irecv, rcv[0], lo)]
+                    ops = [dist.P2POp(dist.isend, snd, lo, group=halo_pg), dist.P2POp(dist.isend, snd, hi, group=halo_pg),
+                           dist.P2POp(dist.irecv, rcv[1], hi, group=halo_pg), dist.P2POp(dist.irecv, rcv[0], lo, group=halo_pg)]
                 else:
-                    ops = [dist.P2POp(dist.isend, snd, lo), dist.P2POp(dist.irecv, rcv[0], lo),
-                           dist.P2POp(dist.isend, snd, hi), dist.P2POp(dist.irecv, rcv[1], hi)]
+                    ops = [dist.P2POp(dist.isend, snd, lo, group=halo_pg), dist.P2POp(dist.irecv, rcv[0], lo, group=halo_pg),
+                           dist.P2POp(dist.isend, snd, hi, group=halo_pg), dist.P2POp(dist.irecv, rcv[1], hi, group=halo_pg)]
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
                 word = torch.tensor([1.0 + rank], dtype=torch.float64, device="cuda")
-                dist.all_reduce(word, op=dist.ReduceOp.MIN)
+                dist.all_reduce(word, op=dist.ReduceOp.MIN, group=halo_pg)
                 torch.cuda.synchronize()
                 if float(rcv[0][0].item()) != float(lo) or float(rcv[1][0].item()) != float(hi) or float(word.item()) != 1.0:
                     raise RuntimeError("RCCL pre-flight: wrong data received")
-            except Exception as e:       # noqa: BLE001 - any failure of the device transport selects the fallback
+            except Exception as e:       # noqa: BLE001
                 print(f"[bench rank {rank}] RCCL pre-flight failed: {e!r}", file=sys.stderr, flush=True)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo)
-            if int(flag.item()) == 0:
-                staged_pg = gloo
-                transport = "gloo, host-staged (RCCL pre-flight failed on at least one rank)"
-        one = torch.ones(1, dtype=torch.int64, device="cpu" if (args.rehearse or staged_pg is not None) else "cuda")
-        dist.all_reduce(one, op=dist.ReduceOp.SUM, group=staged_pg)     # the collective backend really spans `world` ranks
+                ok = False
+            if agree(ok):
+                kind, transport = "rccl", "RCCL, device buffers (torch.distributed from the exchange callbacks)"
+            else:
+                halo_pg = None
+        # 3. host-staged buffers over gloo: slow, always available, still a valid measurement
+        if kind == "none":
+            kind = "gloo"
+            transport = ("gloo, host-staged (rehearsal on one GPU)" if args.rehearse
+                         else "gloo, host-staged (neither the device-side transport nor RCCL passed its pre-flight)")
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)     # the control group really spans `world` ranks
         ranks_seen = int(one.item())
     reps = 1 if args.no_extras else max(1, args.reps)
 
@@ -250,12 +271,10 @@ def main():
         torch.cuda.synchronize()
         return 10 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-    host_side = args.rehearse or staged_pg is not None
-
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(group=staged_pg)
+            dist.barrier()
             torch.cuda.synchronize()
 
     def measure(workload, n, fp, steps, warmup, nrep, copy_gbs):
@@ -266,7 +285,8 @@ def main():
         grid = block_grid(dim, world)
         P = build_problem(workload, n, grid, fp_mode, not args.no_corner_transport)
         m = MFP(P, device=local, rank=rank, world=world, stream=0, fused=(3 if args.tiled_hydro else not args.no_fused),
-                exchange_device=("cpu" if host_side and world > 1 else None), overlap=args.overlap, pg=staged_pg)
+                exchange_device=("cpu" if kind in ("gloo", "peer") else None), overlap=args.overlap, pg=halo_pg,
+                transport=("peer" if kind == "peer" else "callback"))
         m.init_data()
         m.run(warmup)
         fused = m.last_advance_path()
@@ -283,9 +303,9 @@ def main():
             m.run(steps)
             sync()
             el = time.perf_counter() - t0
-            t = torch.tensor([el], dtype=torch.float64, device="cpu" if host_side else "cuda")
+            t = torch.tensor([el], dtype=torch.float64)
             if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=staged_pg)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
             blocks.append(float(t.item()))
         prof = [m.profile_read(s) for s in range(4)]
         m.profile_enable(False)
@@ -411,7 +431,7 @@ def main():
             others[f"{w}:{n}"] = {k: r[k] for k in keep if k in r}
         out["other_workloads"] = others
     if world > 1:
-        dist.barrier(group=staged_pg)
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

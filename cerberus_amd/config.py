@@ -333,6 +333,22 @@ class Problem:
             out.append((self.state_index[st], species))
         return out
 
+    def elliptic_face_types(self, field_state):
+        """(bc_B, bc_D): the physical boundary type (FieldState::bc_names, MFP_field.cpp:36-40) of the field's
+        fill_B_bc / fill_D_bc entry per face [2 * dim + side] - what Elliptic's set_field_bcs (MFP_elliptic.cpp:83-122)
+        reads from phys_fill_bc[Bx] / phys_fill_bc[Dx]; 'interior' (0) in periodic directions (MFP_field.cpp:415-420)."""
+        from . import bc as bcmod
+        sd = self.cfg["states"][self.state_names[field_state]]
+        out = []
+        for key in ("fill_B_bc", "fill_D_bc"):
+            t = [0] * 6
+            for d in range(self.dim):
+                for side in range(2):
+                    name = bcmod._get(sd.get("bc", {}), d, side, key, "outflow")
+                    t[2 * d + side] = 0 if self.periodic[d] else bcmod.FIELD_BC_NAMES[name]
+            out.append(t)
+        return tuple(out)
+
     def n_comp(self, s):
         sd = self.cfg["states"][self.state_names[s]]
         return 5 + gas_n_tracers(sd["gas"]) if sd["type"] == "hydro" else 10

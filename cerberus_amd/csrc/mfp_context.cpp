@@ -1924,13 +1924,25 @@ int cmfp_state_set_face_values(cmfp_context* c, int s, int dim, int side, int pr
 }
 
 // Elliptic::project_divergence_field MFP_elliptic.cpp:667-782
-int cmfp_elliptic_project(cmfp_context* c, int fs, int n_species, const int* species) {
+int cmfp_elliptic_project_bc(cmfp_context* c, int fs, int n_species, const int* species, const int* bc_B, const int* bc_D) {
     int r;
     if ((r = check_ctx(c))) return r;
     if (fs < 0 || fs >= (int)c->states.size() || c->states[fs].sp.kind != CMFP_STATE_FIELD)
         return fail(c, CMFP_ERR_INVALID, "An invalid state has been defined for the 'elliptic' action");  // :66
     if (n_species < 0 || n_species > 8 || (n_species && !species)) return fail(c, CMFP_ERR_INVALID, "bad species list");
-    if (const char* why = cmfp_ell::check(c->g, c->geom.is_periodic, c->split)) return fail(c, CMFP_ERR_INVALID, why);
+    if (c->g.dim < 2) return CMFP_OK;  // "MLNodeLaplacian not implemented for 1D": the reference compiles the body out (:641-650)
+    int pb[2][3][2];
+    bool any_face = false;
+    for (int d = 0; d < 3; ++d)
+        for (int side = 0; side < 2; ++side) {
+            // without a table every face is 'outflow', the default of the field's bc entries (MFP_field.cpp:323-325)
+            pb[0][d][side] = bc_B ? bc_B[2 * d + side] : CMFP_PHYSBC_OUTFLOW;
+            pb[1][d][side] = bc_D ? bc_D[2 * d + side] : CMFP_PHYSBC_OUTFLOW;
+            if (d < c->g.dim && !c->geom.is_periodic[d]) any_face = true;
+        }
+    cmfp_ell::Grid EB, ED;
+    if (const char* why = cmfp_ell::make_grid(c->g, c->geom.is_periodic, c->split, pb[0], EB)) return fail(c, CMFP_ERR_INVALID, why);
+    if (const char* why = cmfp_ell::make_grid(c->g, c->geom.is_periodic, c->split, pb[1], ED)) return fail(c, CMFP_ERR_INVALID, why);
     cmfp_ell::ChargeArgs q;
     std::memset(&q, 0, sizeof(q));
     q.ns = n_species;
@@ -1952,15 +1964,24 @@ int cmfp_elliptic_project(cmfp_context* c, int fs, int n_species, const int* spe
         }
     }
     q.sc = c->g.sc;
-    HIPCHK(c, cmfp_ell::setup(c->g, c->ell));
     double* F = c->states[fs].new_data;
     const long sc = c->g.sc;
     q.ep = F + 9 * sc;
-    q.cd_scale = c->params.Larmor / (c->params.Debye * c->params.Debye * c->params.lightspeed);  // :688
-    cmfp_ell::project(c->g, c->ell, F + 3 * sc, F + 7 * sc, nullptr, c->stream);  // B with psi   :678-682
-    cmfp_ell::project(c->g, c->ell, F + 0 * sc, F + 6 * sc, &q, c->stream);       // D with phi   :775-780
+    q.cd_scale = c->params.Larmor / (c->params.Debye * c->params.Debye * c->params.lightspeed);  // :685
+    // the cells beyond a physical face enter the nodal divergence: FillPatch of the vector with one ghost layer (:897-904)
+    if (any_face && (r = fill_patch(c, fs))) return r;
+    HIPCHK(c, cmfp_ell::setup(EB, c->g, c->ell));
+    cmfp_ell::project(c->g, EB, c->ell, F + 3 * sc, F + 7 * sc, nullptr, c->stream);  // B with psi   :677-681
+    // the second solve's FillPatch sees the projected B only through components it does not read; D is unchanged so far
+    HIPCHK(c, cmfp_ell::setup(ED, c->g, c->ell));
+    cmfp_ell::project(c->g, ED, c->ell, F + 0 * sc, F + 6 * sc, &q, c->stream);       // D with phi   :775-780
     std::fill(c->red_valid.begin(), c->red_valid.end(), 0);  // B changed: the cyclotron dt limit has to be taken again
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, CMFP_ERR_HIP, std::string("divergence projection launch: ") + hipGetErrorString(e));
     return CMFP_OK;
+}
+int cmfp_elliptic_project(cmfp_context* c, int fs, int n_species, const int* species) {
+    return cmfp_elliptic_project_bc(c, fs, n_species, species, nullptr, nullptr);
 }
 
 int cmfp_set_fused(cmfp_context* c, int enable) {

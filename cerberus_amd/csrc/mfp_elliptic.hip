@@ -1,4 +1,4 @@
-// mfp_elliptic.hip — divergence projection of the Maxwell state on a periodic uniform block:
+// mfp_elliptic.hip — divergence projection of the Maxwell state on a uniform block:
 // Elliptic::project_divergence_field + solve_divergence (actions/MFP_elliptic.cpp:636-782, 784-964).
 //
 // The reference hands the solve to AMReX: a cell-centred vector V is projected with the *nodal* operators of
@@ -9,14 +9,25 @@
 //     phi_cc = average of the cell's nodes (average_node_to_cellcenter)
 // D and G are (difference along d) x (average across the other directions); L is the FE stencil
 // ([1 1 1; 1 -8 1; 1 1 1] / 3h^2 in 2-D for dx = dy), not D G: the projection is approximate to O(h^2), as the
-// reference's own comment says (MFP_elliptic.cpp:806).  On a periodic block L is diagonal in Fourier space, so the
-// solve is exact here (the reference iterates MLMG to reltol 1e-8): parity with the reference is unpinned.
-// Power-of-two cells per periodic dimension (radix-2 FFT in LDS, one line per workgroup).
+// reference's own comment says (MFP_elliptic.cpp:806).
+//
+// Domain faces (set_field_bcs, MFP_elliptic.cpp:83-122: outflow / symmetry -> Neumann, inflow -> homogeneous
+// Dirichlet).  AMReX mirrors the ghost nodes of a Neumann face (the boundary row is the doubled one-sided stencil),
+// keeps phi = 0 on a Dirichlet face, and in compRHS lets the cells beyond a Neumann face contribute their normal
+// component only (mlndlap_divu) and doubles the node's value per Neumann face (mlndlap_impose_neumann_bc).  With
+// those rules the operator on the n + 1 nodes of a direction equals the periodic operator on the mirrored
+// extension of that direction (2 n points for two faces of one kind, 4 n for one of each; negative mirror image
+// about a Dirichlet face), which is diagonal in Fourier space: the right-hand side is evaluated on the true nodes
+// with the boundary rules, copied onto the extension with the mirror signs, and the solve is the periodic one.
+// Exact to rounding (the reference iterates MLMG to reltol 1e-8): parity with the reference is unpinned.
+// Radix-2 FFT in LDS (one line per workgroup) where the extension length is a power of two, else a direct
+// O(P^2) transform of the line; at most 8192 points per line.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <vector>
 
+#include "../../include/cerberus_mfp.h"
 #include "mfp_elliptic.h"
 
 namespace cmfp_ell {
@@ -24,7 +35,37 @@ using cmfp::Geo;
 
 __device__ __forceinline__ int wrap(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
-// S_cc = -cd_scale * (sum_s rho_s q_s / m_s) / ep on the valid cells (MFP_elliptic.cpp:700-765:
+// point e of a direction's periodic extension -> true node (0 .. n; 0 .. n - 1 where periodic) and mirror sign
+__device__ __forceinline__ void ext_map(int e, int n, int lo, int hi, int& node, double& sgn) {
+    sgn = 1.0;
+    if (lo == PERIODIC) {
+        node = e;
+        return;
+    }
+    if (lo == hi) {  // period 2 n
+        if (e <= n) {
+            node = e;
+        } else {
+            node = 2 * n - e;
+            if (lo == DIRICHLET) sgn = -1.0;
+        }
+        return;
+    }
+    // one face of each kind: period 4 n; mirror about node 0 first, then about node n
+    int e1 = e;
+    if (e > 2 * n) {
+        e1 = 4 * n - e;
+        if (lo == DIRICHLET) sgn = -1.0;
+    }
+    if (e1 <= n) {
+        node = e1;
+    } else {
+        node = 2 * n - e1;
+        if (hi == DIRICHLET) sgn = -sgn;
+    }
+}
+
+// S_cc = -cd_scale * (sum_s rho_s q_s / m_s) / ep on the valid cells (MFP_elliptic.cpp:722-766:
 // HydroState::calc_current_and_charge, divide by ep, mult(-cd_scale))
 __global__ void k_ell_charge(Geo g, ChargeArgs a, double* __restrict__ S) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,44 +100,66 @@ __global__ void k_ell_charge(Geo g, ChargeArgs a, double* __restrict__ S) {
     S[t] = cd * (-a.cd_scale);
 }
 
-// rhs at node (i, j, k) = lower corner of cell (i, j, k), periodic: compRHS
-__global__ void k_ell_rhs(Geo g, const double* __restrict__ V, const double* __restrict__ S, Cplx* __restrict__ out) {
+// compRHS on the points of the extension: the value of the true node (its cells: lower corner of cell (i, j, k)
+// is node (i, j, k)) times the mirror sign.  V carries one filled ghost layer where the domain has faces.
+__global__ void k_ell_rhs(Geo g, Grid E, const double* __restrict__ V, const double* __restrict__ S, Cplx* __restrict__ out) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
-    const long nn = (long)n0 * n1 * n2;
-    if (t >= nn) return;
-    const int i = (int)(t % n0), j = (int)((t / n0) % n1), k = (int)(t / ((long)n0 * n1));
-    const int im = wrap(i - 1, n0), jm = wrap(j - 1, n1), km = g.dim == 3 ? wrap(k - 1, n2) : 0;
-    const double* vx = V;
-    const double* vy = V + g.sc;
-    const double* vz = V + 2 * g.sc;
-    double r;
-    if (g.dim == 2) {
-        const double fx = 0.5 / g.dx[0], fy = 0.5 / g.dx[1];
-        r = fx * (-vx[g.at(im, jm, 0)] + vx[g.at(i, jm, 0)] - vx[g.at(im, j, 0)] + vx[g.at(i, j, 0)]) +
-            fy * (-vy[g.at(im, jm, 0)] - vy[g.at(i, jm, 0)] + vy[g.at(im, j, 0)] + vy[g.at(i, j, 0)]);
-        if (S) r += 0.25 * (S[(long)jm * n0 + im] + S[(long)jm * n0 + i] + S[(long)j * n0 + im] + S[(long)j * n0 + i]);
-    } else {
-        const double fx = 0.25 / g.dx[0], fy = 0.25 / g.dx[1], fz = 0.25 / g.dx[2];
-        double sx = 0, sy = 0, sz = 0, ss = 0;
-        const int I[2] = {im, i}, J[2] = {jm, j}, K[2] = {km, k};
-        for (int c = 0; c < 2; ++c)
-            for (int b = 0; b < 2; ++b)
-                for (int a = 0; a < 2; ++a) {
-                    const long q = g.at(I[a], J[b], K[c]);
-                    sx += (a ? 1.0 : -1.0) * vx[q];
-                    sy += (b ? 1.0 : -1.0) * vy[q];
-                    sz += (c ? 1.0 : -1.0) * vz[q];
-                    if (S) ss += S[((long)K[c] * n1 + J[b]) * n0 + I[a]];
-                }
-        r = fx * sx + fy * sy + fz * sz;
-        if (S) r += 0.125 * ss;
+    if (t >= E.total()) return;
+    int e[3] = {(int)(t % E.P[0]), (int)((t / E.P[0]) % E.P[1]), (int)(t / ((long)E.P[0] * E.P[1]))};
+    int node[3] = {0, 0, 0};
+    double sgn = 1.0, twice = 1.0;
+    bool masked = false;
+    for (int d = 0; d < E.dim; ++d) {
+        double s;
+        ext_map(e[d], E.n[d], E.bc[d][0], E.bc[d][1], node[d], s);
+        sgn *= s;
+        if (E.bc[d][0] != PERIODIC) {
+            if (node[d] == 0) {
+                if (E.bc[d][0] == DIRICHLET) masked = true;
+                else twice *= 2.0;  // mlndlap_impose_neumann_bc
+            } else if (node[d] == E.n[d]) {
+                if (E.bc[d][1] == DIRICHLET) masked = true;
+                else twice *= 2.0;
+            }
+        }
+    }
+    double r = 0.0;
+    if (!masked) {
+        const double fac = E.dim == 2 ? 0.5 : 0.25;
+        double sum[3] = {0.0, 0.0, 0.0}, ss = 0.0;
+        const int ncorner = 1 << E.dim;
+        for (int q = 0; q < ncorner; ++q) {
+            int c[3] = {0, 0, 0};
+            bool outside[3] = {false, false, false};
+            for (int d = 0; d < E.dim; ++d) {
+                const int a = (q >> d) & 1;
+                c[d] = node[d] - 1 + a;
+                if (E.bc[d][0] == PERIODIC) c[d] = wrap(c[d], E.n[d]);
+                else outside[d] = c[d] < 0 || c[d] >= E.n[d];  // a ghost cell beyond a Neumann face
+            }
+            const long cell = g.at(c[0], c[1], c[2]);
+            bool any_out = false;
+            for (int d = 0; d < E.dim; ++d) any_out = any_out || outside[d];
+            for (int d = 0; d < E.dim; ++d) {
+                // the nodal divergence does not see the tangential components of a cell beyond the face (mlndlap_divu)
+                bool other_out = false;
+                for (int f = 0; f < E.dim; ++f)
+                    if (f != d && outside[f]) other_out = true;
+                if (other_out) continue;
+                const double v = V[cell + d * g.sc];
+                sum[d] += ((q >> d) & 1) ? v : -v;
+            }
+            if (S && !any_out) ss += S[((long)c[2] * g.n[1] + c[1]) * g.n[0] + c[0]];  // the source is zero beyond the domain
+        }
+        for (int d = 0; d < E.dim; ++d) r += (fac / E.dx[d]) * sum[d];
+        if (S) r += (E.dim == 2 ? 0.25 : 0.125) * ss;
+        r *= twice * sgn;
     }
     out[t].re = r;
     out[t].im = 0.0;
 }
 
-// radix-2 FFT of one line of N = 2^lg complex values per workgroup, in LDS (N <= 4096: 64 KB)
+// radix-2 FFT of one line of N = 2^lg complex values per workgroup, in LDS
 __global__ __launch_bounds__(256) void k_ell_fft(Cplx* __restrict__ data, int N, int lg, long elem_stride, int na, long stride_a,
                                                   long stride_b, const Cplx* __restrict__ tw, int inverse) {
     extern __shared__ double lds[];
@@ -104,7 +167,7 @@ __global__ __launch_bounds__(256) void k_ell_fft(Cplx* __restrict__ data, int N,
     const int line = blockIdx.x;
     const long base = (long)(line % na) * stride_a + (long)(line / na) * stride_b;
     for (int t = threadIdx.x; t < N; t += blockDim.x) {
-        const unsigned rev = __brev((unsigned)t) >> (32 - lg);
+        const unsigned rev = lg ? __brev((unsigned)t) >> (32 - lg) : 0u;
         x[rev] = data[base + (long)t * elem_stride];
     }
     __syncthreads();
@@ -127,23 +190,48 @@ __global__ __launch_bounds__(256) void k_ell_fft(Cplx* __restrict__ data, int N,
     for (int t = threadIdx.x; t < N; t += blockDim.x) data[base + (long)t * elem_stride] = x[t];
 }
 
+// direct transform of one line of any length N (tw: exp(-2 pi i m / N), m < N): O(N^2) per line
+__global__ __launch_bounds__(256) void k_ell_dft(Cplx* __restrict__ data, int N, long elem_stride, int na, long stride_a, long stride_b,
+                                                  const Cplx* __restrict__ tw, int inverse) {
+    extern __shared__ double lds[];
+    Cplx* x = reinterpret_cast<Cplx*>(lds);
+    const int line = blockIdx.x;
+    const long base = (long)(line % na) * stride_a + (long)(line / na) * stride_b;
+    for (int t = threadIdx.x; t < N; t += blockDim.x) x[t] = data[base + (long)t * elem_stride];
+    __syncthreads();
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+        double ar = 0.0, ai = 0.0;
+        int m = 0;  // (j k) mod N
+        for (int j = 0; j < N; ++j) {
+            Cplx w = tw[m];
+            if (inverse) w.im = -w.im;
+            const Cplx v = x[j];
+            ar += v.re * w.re - v.im * w.im;
+            ai += v.re * w.im + v.im * w.re;
+            m += k;
+            if (m >= N) m -= N;
+        }
+        data[base + (long)k * elem_stride].re = ar;  // the line was copied to LDS: nobody reads `data` any more
+        data[base + (long)k * elem_stride].im = ai;
+    }
+}
+
 // phi_hat = rhs_hat / symbol(L) / N_total (the unnormalised inverse transform follows); the mean mode is set to 0
-__global__ void k_ell_solve(Geo g, Cplx* __restrict__ hat) {
+__global__ void k_ell_solve(Grid E, Cplx* __restrict__ hat) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
-    const long nn = (long)n0 * n1 * n2;
+    const long nn = E.total();
     if (t >= nn) return;
-    const int i = (int)(t % n0), j = (int)((t / n0) % n1), k = (int)(t / ((long)n0 * n1));
+    const int i = (int)(t % E.P[0]), j = (int)((t / E.P[0]) % E.P[1]), k = (int)(t / ((long)E.P[0] * E.P[1]));
     const double PI2 = 6.283185307179586;
-    const double cx = cos(PI2 * i / n0), cy = cos(PI2 * j / n1), cz = g.dim == 3 ? cos(PI2 * k / n2) : 1.0;
+    const double cx = cos(PI2 * i / E.P[0]), cy = cos(PI2 * j / E.P[1]), cz = E.dim == 3 ? cos(PI2 * k / E.P[2]) : 1.0;
     // 1-D stiffness (2 - 2 cos) / h^2 and mass (4 + 2 cos) / 6 symbols of the linear elements
-    const double Kx = (2.0 - 2.0 * cx) / (g.dx[0] * g.dx[0]), Ky = (2.0 - 2.0 * cy) / (g.dx[1] * g.dx[1]);
+    const double Kx = (2.0 - 2.0 * cx) / (E.dx[0] * E.dx[0]), Ky = (2.0 - 2.0 * cy) / (E.dx[1] * E.dx[1]);
     const double Mx = (4.0 + 2.0 * cx) / 6.0, My = (4.0 + 2.0 * cy) / 6.0;
     double sym;
-    if (g.dim == 2) {
+    if (E.dim == 2) {
         sym = -(Kx * My + Mx * Ky);
     } else {
-        const double Kz = (2.0 - 2.0 * cz) / (g.dx[2] * g.dx[2]), Mz = (4.0 + 2.0 * cz) / 6.0;
+        const double Kz = (2.0 - 2.0 * cz) / (E.dx[2] * E.dx[2]), Mz = (4.0 + 2.0 * cz) / 6.0;
         sym = -(Kx * My * Mz + Mx * Ky * Mz + Mx * My * Kz);
     }
     const double f = (i == 0 && j == 0 && k == 0) ? 0.0 : 1.0 / (sym * (double)nn);
@@ -152,74 +240,115 @@ __global__ void k_ell_solve(Geo g, Cplx* __restrict__ hat) {
 }
 
 // V -= G phi at the cell centres; phi_cc = average of the cell's nodes
-__global__ void k_ell_apply(Geo g, double* __restrict__ V, double* __restrict__ phi_cc, const Cplx* __restrict__ phi) {
+__global__ void k_ell_apply(Geo g, Grid E, double* __restrict__ V, double* __restrict__ phi_cc, const Cplx* __restrict__ phi) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
-    const long nn = (long)n0 * n1 * n2;
-    if (t >= nn) return;
-    const int i = (int)(t % n0), j = (int)((t / n0) % n1), k = (int)(t / ((long)n0 * n1));
-    const int ip = wrap(i + 1, n0), jp = wrap(j + 1, n1), kp = g.dim == 3 ? wrap(k + 1, n2) : 0;
-    const long c = g.at(i, j, k);
-    auto P = [&](int a, int b, int cc) { return phi[((long)cc * n1 + b) * n0 + a].re; };
-    if (g.dim == 2) {
-        const double p00 = P(i, j, 0), p10 = P(ip, j, 0), p01 = P(i, jp, 0), p11 = P(ip, jp, 0);
-        const double gx = (0.5 / g.dx[0]) * (-p00 + p10 - p01 + p11);
-        const double gy = (0.5 / g.dx[1]) * (-p00 - p10 + p01 + p11);
-        V[c] += -gx;
-        V[c + g.sc] += -gy;
-        phi_cc[c] = 0.25 * (p00 + p10 + p01 + p11);
-    } else {
-        const int I[2] = {i, ip}, J[2] = {j, jp}, K[2] = {k, kp};
-        double gx = 0, gy = 0, gz = 0, av = 0;
-        for (int cc = 0; cc < 2; ++cc)
-            for (int b = 0; b < 2; ++b)
-                for (int a = 0; a < 2; ++a) {
-                    const double p = P(I[a], J[b], K[cc]);
-                    gx += (a ? 1.0 : -1.0) * p;
-                    gy += (b ? 1.0 : -1.0) * p;
-                    gz += (cc ? 1.0 : -1.0) * p;
-                    av += p;
-                }
-        V[c] += -(0.25 / g.dx[0]) * gx;
-        V[c + g.sc] += -(0.25 / g.dx[1]) * gy;
-        V[c + 2 * g.sc] += -(0.25 / g.dx[2]) * gz;
-        phi_cc[c] = 0.125 * av;
+    const long nc = (long)n0 * n1 * n2;
+    if (t >= nc) return;
+    const int c3[3] = {(int)(t % n0), (int)((t / n0) % n1), (int)(t / ((long)n0 * n1))};
+    const long c = g.at(c3[0], c3[1], c3[2]);
+    double gsum[3] = {0.0, 0.0, 0.0}, av = 0.0;
+    const int ncorner = 1 << E.dim;
+    for (int q = 0; q < ncorner; ++q) {
+        int nd[3] = {0, 0, 0};
+        for (int d = 0; d < E.dim; ++d) {
+            nd[d] = c3[d] + ((q >> d) & 1);
+            if (E.bc[d][0] == PERIODIC) nd[d] = wrap(nd[d], E.n[d]);  // else node n is point n of the extension
+        }
+        const double p = phi[((long)nd[2] * E.P[1] + nd[1]) * E.P[0] + nd[0]].re;
+        av += p;
+        for (int d = 0; d < E.dim; ++d) gsum[d] += ((q >> d) & 1) ? p : -p;
     }
+    const double fac = E.dim == 2 ? 0.5 : 0.25;
+    for (int d = 0; d < E.dim; ++d) V[c + d * g.sc] += -(fac / E.dx[d]) * gsum[d];
+    phi_cc[c] = (E.dim == 2 ? 0.25 : 0.125) * av;
 }
 
-static bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 static int ilog2(int n) {
     int l = 0;
     while ((1 << l) < n) ++l;
     return l;
 }
+static constexpr int MAX_LINE = 8192;  // points per transformed line: 128 KB of LDS
 
-const char* check(const Geo& g, const int periodic[3], const int split[3]) {
+const char* make_grid(const Geo& g, const int periodic[3], const int split[3], const int phys_bc[3][2], Grid& E) {
+    E = Grid();
+    E.dim = g.dim;
+    for (int d = 0; d < 3; ++d) {
+        E.n[d] = d < g.dim ? g.n[d] : 1;
+        E.P[d] = 1;
+        E.pow2[d] = 1;
+        E.dx[d] = g.dx[d];
+        E.bc[d][0] = E.bc[d][1] = PERIODIC;
+    }
     if (g.dim < 2) return "the nodal projection is not defined in 1-D (MFP_elliptic.cpp:640)";
     for (int d = 0; d < g.dim; ++d) {
-        if (!periodic[d]) return "divergence projection: periodic dimensions only (wall / outflow faces need the AMReX solver's boundary stencils)";
         if (split[d]) return "divergence projection: the block must span the domain (single rank)";
-        if (!pow2(g.n[d]) || g.n[d] > 4096 || g.n[d] < 2) return "divergence projection: cells per dimension must be a power of two in [2, 4096]";
+        if (g.n[d] < 2) return "divergence projection: at least two cells per dimension";
+        if (periodic[d]) {
+            E.P[d] = g.n[d];
+        } else {
+            if (g.ng[d] < 1) return "divergence projection: the field needs a ghost layer on a domain with physical faces";
+            for (int side = 0; side < 2; ++side) {
+                switch (phys_bc[d][side]) {  // set_field_bcs, MFP_elliptic.cpp:93-119
+                case CMFP_PHYSBC_OUTFLOW:
+                case CMFP_PHYSBC_SYMMETRY: E.bc[d][side] = NEUMANN; break;
+                case CMFP_PHYSBC_INFLOW: E.bc[d][side] = DIRICHLET; break;
+                case CMFP_PHYSBC_ASYMMETRY:
+                    return "divergence projection: an 'asymmetry' face maps to LinOpBCType::reflect_odd in the reference "
+                           "(MFP_elliptic.cpp:102-104 through the value 4 of MFP_field.cpp:40), which AMReX's nodal solver does not define";
+                default: return "divergence projection: a non-periodic face needs one of inflow / outflow / symmetry";
+                }
+            }
+            E.P[d] = (E.bc[d][0] == E.bc[d][1] ? 2 : 4) * g.n[d];
+        }
+        E.pow2[d] = is_pow2(E.P[d]);
+        if (E.P[d] > MAX_LINE)
+            return "divergence projection: more than 8192 points per transformed line (cells of a periodic direction, twice the "
+                   "cells of a direction between two faces of one kind, four times between a Neumann and a Dirichlet face)";
     }
     return nullptr;
 }
 
-hipError_t setup(const Geo& g, Work& w) {
-    const long nn = (long)g.n[0] * g.n[1] * g.n[2];
+hipError_t setup(const Grid& E, const Geo& g, Work& w) {
+    const long nn = E.total();
     hipError_t e;
-    if (!w.nodes && (e = hipMalloc((void**)&w.nodes, sizeof(Cplx) * nn)) != hipSuccess) return e;
-    if (!w.S && (e = hipMalloc((void**)&w.S, sizeof(double) * nn)) != hipSuccess) return e;
-    for (int d = 0; d < g.dim; ++d) {
-        if (w.tw[d]) continue;
-        const int N = g.n[d];
-        std::vector<Cplx> h(N / 2 > 0 ? N / 2 : 1);
-        for (int q = 0; q < N / 2; ++q) {
+    if (w.nodes_cap < nn) {
+        if (w.nodes) (void)hipFree(w.nodes);
+        w.nodes = nullptr;
+        w.nodes_cap = 0;
+        if ((e = hipMalloc((void**)&w.nodes, sizeof(Cplx) * nn)) != hipSuccess) return e;
+        w.nodes_cap = nn;
+    }
+    const long ncell = (long)g.n[0] * g.n[1] * g.n[2];
+    if (!w.S && (e = hipMalloc((void**)&w.S, sizeof(double) * ncell)) != hipSuccess) return e;
+    for (int d = 0; d < E.dim; ++d) {
+        const int N = E.P[d];
+        const int len = E.pow2[d] ? (N / 2 > 0 ? N / 2 : 1) : N;  // radix-2: exp(-2 pi i q / N), q < N / 2; direct: q < N
+        if (w.tw[d] && w.tw_len[d] == (E.pow2[d] ? -N : N)) continue;
+        if (w.tw[d]) (void)hipFree(w.tw[d]);
+        w.tw[d] = nullptr;
+        std::vector<Cplx> h((size_t)len);
+        for (int q = 0; q < len; ++q) {
             const double a = -6.283185307179586476925286766559 * q / N;
             h[q].re = std::cos(a);
             h[q].im = std::sin(a);
         }
         if ((e = hipMalloc((void**)&w.tw[d], sizeof(Cplx) * h.size())) != hipSuccess) return e;
         if ((e = hipMemcpy(w.tw[d], h.data(), sizeof(Cplx) * h.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+        w.tw_len[d] = E.pow2[d] ? -N : N;
+    }
+    // lines of more than 4096 points need more than the default 64 KB of dynamic LDS
+    static bool attr = false;
+    if (!attr) {
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ell_fft), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(sizeof(Cplx) * MAX_LINE))) != hipSuccess)
+            return e;
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ell_dft), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(sizeof(Cplx) * MAX_LINE))) != hipSuccess)
+            return e;
+        attr = true;
     }
     return hipSuccess;
 }
@@ -232,29 +361,34 @@ void release(Work& w) {
     w = Work();
 }
 
-static void fft_all(const Geo& g, Work& w, int inverse, hipStream_t st) {
-    const long str[3] = {1, g.n[0], (long)g.n[0] * g.n[1]};
-    for (int d = 0; d < g.dim; ++d) {
-        const int N = g.n[d];
+static void fft_all(const Grid& E, Work& w, int inverse, hipStream_t st) {
+    const long str[3] = {1, E.P[0], (long)E.P[0] * E.P[1]};
+    for (int d = 0; d < E.dim; ++d) {
+        const int N = E.P[d];
         const int a = (d + 1) % 3, b = (d + 2) % 3;
-        const int na = g.n[a], nb = g.n[b];
-        const int threads = N / 2 < 256 ? (N / 2 < 64 ? 64 : N / 2) : 256;
-        hipLaunchKernelGGL(k_ell_fft, dim3(na * nb), dim3(threads), sizeof(Cplx) * N, st, w.nodes, N, ilog2(N), str[d], na, str[a], str[b],
-                           w.tw[d], inverse);
+        const int na = E.P[a], nb = E.P[b];
+        if (E.pow2[d]) {
+            const int threads = N / 2 < 256 ? (N / 2 < 64 ? 64 : N / 2) : 256;
+            hipLaunchKernelGGL(k_ell_fft, dim3(na * nb), dim3(threads), sizeof(Cplx) * N, st, w.nodes, N, ilog2(N), str[d], na, str[a], str[b],
+                               w.tw[d], inverse);
+        } else {
+            hipLaunchKernelGGL(k_ell_dft, dim3(na * nb), dim3(256), sizeof(Cplx) * N, st, w.nodes, N, str[d], na, str[a], str[b], w.tw[d],
+                               inverse);
+        }
     }
 }
 
 // one solve_divergence (MFP_elliptic.cpp:784-964): V = the three components starting at V (component stride g.sc),
 // phi_cc = the cleaning potential's component, charge = nullptr for the B field
-void project(const Geo& g, Work& w, double* V, double* phi_cc, const ChargeArgs* charge, hipStream_t st) {
-    const long nn = (long)g.n[0] * g.n[1] * g.n[2];
-    const dim3 grid((unsigned)((nn + 255) / 256)), block(256);
-    if (charge) hipLaunchKernelGGL(k_ell_charge, grid, block, 0, st, g, *charge, w.S);
-    hipLaunchKernelGGL(k_ell_rhs, grid, block, 0, st, g, V, charge ? w.S : nullptr, w.nodes);
-    fft_all(g, w, 0, st);
-    hipLaunchKernelGGL(k_ell_solve, grid, block, 0, st, g, w.nodes);
-    fft_all(g, w, 1, st);
-    hipLaunchKernelGGL(k_ell_apply, grid, block, 0, st, g, V, phi_cc, w.nodes);
+void project(const Geo& g, const Grid& E, Work& w, double* V, double* phi_cc, const ChargeArgs* charge, hipStream_t st) {
+    const long nn = E.total(), nc = (long)g.n[0] * g.n[1] * g.n[2];
+    const dim3 block(256), grid_n((unsigned)((nn + 255) / 256)), grid_c((unsigned)((nc + 255) / 256));
+    if (charge) hipLaunchKernelGGL(k_ell_charge, grid_c, block, 0, st, g, *charge, w.S);
+    hipLaunchKernelGGL(k_ell_rhs, grid_n, block, 0, st, g, E, V, charge ? w.S : nullptr, w.nodes);
+    fft_all(E, w, 0, st);
+    hipLaunchKernelGGL(k_ell_solve, grid_n, block, 0, st, E, w.nodes);
+    fft_all(E, w, 1, st);
+    hipLaunchKernelGGL(k_ell_apply, grid_c, block, 0, st, g, E, V, phi_cc, w.nodes);
 }
 
 }  // namespace cmfp_ell

@@ -41,6 +41,7 @@ SYMBOLS = [
     ("cmfp_advance_steps", C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, dp, dp]),
     ("cmfp_advance_steps_static", C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, dp, dp]),
     ("cmfp_elliptic_project", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    ("cmfp_elliptic_project_bc", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("cmfp_last_error_cell", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("cmfp_set_fused", C.c_int, [C.c_void_p, C.c_int]),
     ("cmfp_last_advance_fused", C.c_int, [C.c_void_p]),
@@ -57,6 +58,7 @@ SYMBOLS = [
     ("cmfp_halo_count", C.c_longlong, [C.c_void_p, C.c_int, C.c_int]),
     ("cmfp_halo_pack", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("cmfp_halo_unpack", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("cmfp_hbm_copy_probe", C.c_int, [C.c_int, C.c_void_p, C.c_longlong, C.c_int, dp]),
     ("cmfp_peer_init", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     ("cmfp_peer_open", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("cmfp_peer_set_neighbour", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),

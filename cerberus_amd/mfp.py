@@ -178,7 +178,8 @@ class MFP:
         self._chk(self.L.cmfp_advance(self.h, self.time, dt))
         for fs, species in self._elliptic:     # act->apply_change (MFP_advance.cpp:49)
             arr = (C.c_int * max(1, len(species)))(*species)
-            self._chk(self.L.cmfp_elliptic_project(self.h, fs, len(species), arr))
+            bc_B, bc_D = self.p.elliptic_face_types(fs)
+            self._chk(self.L.cmfp_elliptic_project_bc(self.h, fs, len(species), arr, (C.c_int * 6)(*bc_B), (C.c_int * 6)(*bc_D)))
         self.time += dt
         self.step += 1
 

@@ -305,11 +305,31 @@ int cmfp_advance_steps_static(cmfp_context* ctx, double time, double dt0, int ns
  * with psi, then the D field with phi and the cell-centred source -Larmor / (Debye^2 c) * rho_c / ep, rho_c
  * the charge density of the n_species hydro states listed (the species of the LAST plasma5 action, in sorted-name
  * order, associated with the field: the reference zeroes its charge density inside the loop over the associated
- * actions, :722-766, so earlier plasma5 actions on the same field do not contribute).  The host side calls it after cmfp_advance for every `elliptic` action, where the
- * reference's MFP::advance loops apply_change (MFP_advance.cpp:49).  The reference solves with AMReX's nodal
- * projection (MLNodeLaplacian + MLMG, third party, absent from its tree); here the same nodal operators are
- * solved exactly by FFT on periodic blocks: every dimension periodic, a power of two of cells (<= 4096) per
- * dimension, block = domain, 2-D or 3-D; otherwise CMFP_ERR_INVALID with the reason.  Parity unpinned. */
+ * actions, :722-766, so earlier plasma5 actions on the same field do not contribute).  The host side calls it
+ * after cmfp_advance for every `elliptic` action, where the reference's MFP::advance loops apply_change
+ * (MFP_advance.cpp:49).  The reference solves with AMReX's nodal projection (MLNodeLaplacian + MLMG, third party,
+ * absent from its tree); here the same nodal operators are solved exactly, by FFT on the periodic extension of
+ * the node grid (csrc/mfp_elliptic.hip).
+ * Domain faces: bc_B / bc_D = the physical boundary type (cmfp_phys_bc) of the field's fill_B_bc / fill_D_bc entry
+ * on face [2 * dim + side] - what set_field_bcs (:83-122) reads from phys_fill_bc[Bx] / [Dx]: outflow and
+ * symmetry give a Neumann face, inflow a homogeneous Dirichlet face; NULL = 'outflow' everywhere, the default of
+ * those entries (MFP_field.cpp:323-325); entries of periodic directions are ignored.  'asymmetry' is refused (the
+ * reference maps it to LinOpBCType::reflect_odd, which AMReX's nodal solver does not define).
+ * Limits: 2-D or 3-D (1-D: returns CMFP_OK without doing anything, as the reference's body is compiled out, :641);
+ * block = domain (single rank); at most 8192 points per transformed line = cells of a periodic direction, twice
+ * the cells between two faces of one kind, four times between a Neumann and a Dirichlet face; lines whose length
+ * is not a power of two take a direct O(P^2) transform.  Otherwise CMFP_ERR_INVALID with the reason.
+ * Parity unpinned (no AMReX here, no fixture in the reference). */
+typedef enum {
+    CMFP_PHYSBC_INTERIOR = 0,
+    CMFP_PHYSBC_INFLOW = 1,
+    CMFP_PHYSBC_OUTFLOW = 2,
+    CMFP_PHYSBC_SYMMETRY = 3,
+    CMFP_PHYSBC_ASYMMETRY = 4   /* FieldState::bc_names, MFP_field.cpp:36-40 */
+} cmfp_phys_bc;
+int cmfp_elliptic_project_bc(cmfp_context* ctx, int field_state, int n_species, const int* species_states,
+                             const int* bc_B /* [6] or NULL */, const int* bc_D /* [6] or NULL */);
+/* = cmfp_elliptic_project_bc(ctx, field_state, n_species, species_states, NULL, NULL) */
 int cmfp_elliptic_project(cmfp_context* ctx, int field_state, int n_species, const int* species_states);
 /* Uses hand-fused kernels inside cmfp_advance where available (default 1: the
  * LDS-tiled kernel for 2-D blocks, the tile-free gather kernels for 1-D and 3-D);
@@ -352,6 +372,11 @@ typedef enum {
 } cmfp_prof_slot;
 int cmfp_profile_enable(cmfp_context* ctx, int on);
 int cmfp_profile_read(cmfp_context* ctx, int slot, long long* launches, double* total_ms);
+
+/* Measurement aid (no counterpart in the reference): the HBM bandwidth a device-to-device copy attains on
+ * `device` - 16 bytes per lane and access, read + write bytes counted, the best of three grid sizes, `reps`
+ * passes over two private buffers of `nbytes` each - in GB/s.  bench.py reports it beside the 8 TB/s spec. */
+int cmfp_hbm_copy_probe(int device, void* stream, long long nbytes, int reps, double* gbs);
 
 /* ---- Ghost cells: the FillPatch of Action::get_data (MFP_action.cpp:59) ->
  * FillBC::operator() -> fab_filcc (modules/boundary/MFP_fillbc.cpp:147-172).

@@ -146,6 +146,223 @@ def solve_divergence(V, dx, dim, S_cc=None):
     return Vn, t * (0.5 ** dim)
 
 
+# ---- the same projection on a domain with physical faces ------------------------------------------------------
+# LinOpBCType of a face as Elliptic's set_field_bcs picks it (MFP_elliptic.cpp:83-122): periodic direction ->
+# Periodic; outflow, symmetry -> Neumann; inflow -> Dirichlet (homogeneous).  'asymmetry' maps to
+# LinOpBCType::reflect_odd there (the field's bc_names give it the value of PhysBCType::slipwall,
+# MFP_field.cpp:36-40), which AMReX's nodal solver does not define: refused.
+PERIODIC, NEUMANN, DIRICHLET = 0, 1, 2
+LINOP_OF_PHYS = {"interior": None, "inflow": DIRICHLET, "outflow": NEUMANN, "symmetry": NEUMANN, "asymmetry": None}
+
+
+def _ops_1d(n, h, lo, hi):
+    """stiffness and mass matrices of the linear elements along one direction as the nodal Laplacian applies them:
+    periodic (n nodes), or nodes 0 .. n with the ghost node of a Neumann face mirrored (row doubled) and the node
+    of a Dirichlet face removed.  Returns (K, M, free node indices, weights of the mirrored extension)."""
+    import scipy.sparse as sp
+    if lo == PERIODIC:
+        e = np.ones(n)
+        K = sp.diags([2 * e, -e[1:], -e[1:]], [0, 1, -1], format="lil")
+        M = sp.diags([4 * e, e[1:], e[1:]], [0, 1, -1], format="lil")
+        if n > 1:
+            K[0, n - 1] += -1
+            K[n - 1, 0] += -1
+            M[0, n - 1] += 1
+            M[n - 1, 0] += 1
+        return (K / h ** 2).tocsr(), (M / 6.0).tocsr(), np.arange(n), np.ones(n)
+    m = n + 1
+    e = np.ones(m)
+    K = sp.diags([2 * e, -e[1:], -e[1:]], [0, 1, -1], format="lil")
+    M = sp.diags([4 * e, e[1:], e[1:]], [0, 1, -1], format="lil")
+    w = np.ones(m)
+    if lo == NEUMANN:
+        K[0, 1] = -2
+        M[0, 1] = 2
+        w[0] = 0.5
+    if hi == NEUMANN:
+        K[n, n - 1] = -2
+        M[n, n - 1] = 2
+        w[n] = 0.5
+    free = np.arange(m)
+    if lo == DIRICHLET:
+        free = free[free != 0]
+    if hi == DIRICHLET:
+        free = free[free != n]
+    return (K / h ** 2).tocsr(), (M / 6.0).tocsr(), free, w
+
+
+def solve_divergence_bc(Vg, dx, dim, bc, S_cc=None):
+    """Elliptic::solve_divergence (MFP_elliptic.cpp:784-964) on a domain with physical faces.  Vg: the cell-centred
+    vector [dim][k][j][i] WITH ONE GHOST LAYER in every used dimension, filled as FillPatch fills it (:897-904);
+    bc[d] = (lo, hi) of PERIODIC / NEUMANN / DIRICHLET; S_cc on the valid cells (zero outside, :704-714).
+    AMReX's nodal operators, restated from memory of its published discretisation [AMReX absent: PARITY UNPINNED]:
+      rhs (compRHS): nodal divergence of the cells around a node; at a node on a Neumann face the cells beyond that
+        face contribute their normal component only (mlndlap_divu zeroes the tangential ones) and no source, then
+        the node's value is doubled per Neumann face it lies on (mlndlap_impose_neumann_bc); 0 at Dirichlet nodes;
+      operator: the finite-element stencil with the ghost nodes of a Neumann face mirrored, phi = 0 on Dirichlet
+        faces; without a Dirichlet face the constant is fixed by a zero mean over the mirrored extension.
+    Solved here by assembling the sparse operator and a direct solve - no transform, so that the HIP path
+    (mirrored extension + FFT) is checked against an independent method.  Returns (V_new valid cells, phi_cc)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    n = [Vg.shape[-1 - d] - 2 for d in range(dim)]
+    per = [bc[d][0] == PERIODIC for d in range(dim)]
+    nn = [n[d] if per[d] else n[d] + 1 for d in range(dim)]
+    shape = [1, 1, 1]
+    for d in range(dim):
+        shape[2 - d] = nn[d]
+    fac = 0.5 ** (dim - 1)
+    rhs = np.zeros(shape)
+    node = [np.arange(nn[d]) for d in range(dim)]
+    for corner in range(1 << dim):
+        a = [(corner >> d) & 1 for d in range(dim)]
+        idx, inside = [], []
+        for d in range(dim):
+            c = node[d] - 1 + a[d]
+            if per[d]:
+                idx.append(c % n[d] + 1)
+                inside.append(np.ones(nn[d], dtype=bool))
+            else:
+                idx.append(c + 1)                         # ghost layer at index 0 and n + 1
+                inside.append((c >= 0) & (c < n[d]))
+        def at(arr_d):       # arr_d: [k][j][i] ghosted
+            sel = [slice(1, 2)] * 3 if dim < 3 else None
+            ix = [np.array([0])] * 3
+            for d in range(dim):
+                ix[2 - d] = idx[d]
+            if dim < 3:
+                ix[0] = np.array([0])
+            return arr_d[np.ix_(*ix)]
+        def mask(skip):
+            m = np.ones(shape, dtype=float)
+            for e in range(dim):
+                if e == skip:
+                    continue
+                v = inside[e].astype(float)
+                sh = [1, 1, 1]
+                sh[2 - e] = nn[e]
+                m = m * v.reshape(sh)
+            return m
+        for d in range(dim):
+            sgn = 1.0 if a[d] else -1.0
+            rhs += (fac / dx[d]) * sgn * at(Vg[d]) * mask(d)
+        if S_cc is not None:
+            Sg = np.zeros(Vg.shape[1:])
+            inner = tuple(slice(1, -1) if (2 - ax) < dim else slice(None) for ax in range(3))
+            Sg[inner] = S_cc
+            # periodic directions: the source wraps (FillBoundary inside compRHS); beyond physical faces it is 0
+            for d in range(dim):
+                if per[d]:
+                    ax = 2 - d
+                    lo_g = [slice(None)] * 3
+                    hi_g = [slice(None)] * 3
+                    lo_g[ax], hi_g[ax] = 0, -1
+                    src_lo, src_hi = [slice(None)] * 3, [slice(None)] * 3
+                    src_lo[ax], src_hi[ax] = -2, 1
+                    Sg[tuple(lo_g)] = Sg[tuple(src_lo)]
+                    Sg[tuple(hi_g)] = Sg[tuple(src_hi)]
+            rhs += (0.5 ** dim) * at(Sg) * mask(-1)
+    for d in range(dim):       # mlndlap_impose_neumann_bc; Dirichlet nodes carry no equation
+        sh = [1, 1, 1]
+        sh[2 - d] = nn[d]
+        f = np.ones(nn[d])
+        if not per[d]:
+            if bc[d][0] == NEUMANN:
+                f[0] = 2.0
+            if bc[d][1] == NEUMANN:
+                f[-1] = 2.0
+            if bc[d][0] == DIRICHLET:
+                f[0] = 0.0
+            if bc[d][1] == DIRICHLET:
+                f[-1] = 0.0
+        rhs = rhs * f.reshape(sh)
+    ops = [_ops_1d(n[d], dx[d], bc[d][0], bc[d][1]) for d in range(dim)]
+    ident = [sp.identity(1, format="csr")] * 3
+
+    def kron3(mats):     # index ((k) nn1 + j) nn0 + i  ->  kron(z, kron(y, x))
+        full = [sp.identity(1, format="csr")] * 3
+        for d in range(dim):
+            full[d] = mats[d]
+        return sp.kron(full[2], sp.kron(full[1], full[0], format="csr"), format="csr")
+    L = None
+    for d in range(dim):
+        term = kron3([ops[e][0] if e == d else ops[e][1] for e in range(dim)])
+        L = -term if L is None else L - term
+    wfull = np.ones(shape)
+    free_mask = np.ones(shape, dtype=bool)
+    for d in range(dim):
+        sh = [1, 1, 1]
+        sh[2 - d] = nn[d]
+        wfull = wfull * ops[d][3].reshape(sh)
+        fm = np.zeros(nn[d], dtype=bool)
+        fm[ops[d][2]] = True
+        free_mask = free_mask & fm.reshape(sh)
+    free = np.flatnonzero(free_mask.ravel())
+    w = wfull.ravel()[free]
+    A = sp.diags(w) @ L[free][:, free]                     # symmetric: the assembled element matrices
+    b = w * rhs.ravel()[free]
+    singular = all(bc[d][0] != DIRICHLET and bc[d][1] != DIRICHLET for d in range(dim))
+    if singular:
+        col = sp.csr_matrix(w.reshape(-1, 1))
+        aug = sp.bmat([[A, col], [col.T, None]], format="csc")
+        x = spl.spsolve(aug, np.concatenate([b, [0.0]]))[:-1]
+    else:
+        x = spl.spsolve(A.tocsc(), b)
+    phi = np.zeros(int(np.prod(shape)))
+    phi[free] = x
+    phi = phi.reshape(shape)
+    # V -= G phi at the cell centres, phi_cc = average of the cell's nodes (getFluxes, average_node_to_cellcenter)
+    cell = [np.arange(n[d]) for d in range(dim)]
+    Vn = np.array([Vg[d][tuple(slice(1, -1) if (2 - ax) < dim else slice(None) for ax in range(3))] for d in range(dim)])
+    grad = [np.zeros(Vn.shape[1:]) for _ in range(dim)]
+    avg = np.zeros(Vn.shape[1:])
+    for corner in range(1 << dim):
+        a = [(corner >> d) & 1 for d in range(dim)]
+        ix = [np.array([0])] * 3
+        for d in range(dim):
+            c = cell[d] + a[d]
+            ix[2 - d] = c % nn[d] if per[d] else c
+        p = phi[np.ix_(*ix)]
+        avg += p
+        for d in range(dim):
+            grad[d] += (1.0 if a[d] else -1.0) * p
+    for d in range(dim):
+        Vn[d] = Vn[d] - (fac / dx[d]) * grad[d]
+    return Vn, avg * (0.5 ** dim)
+
+
+def project_divergence_field_bc(Fg, ng, rhos, rs, dx, dim, cd_scale, periodic, bc_B, bc_D):
+    """Elliptic::project_divergence_field (MFP_elliptic.cpp:667-782) on a domain with physical faces.  Fg: the field
+    components [10] with `ng` filled ghost layers in every used dimension (FillPatch, :897-904); rhos: the species'
+    densities on the valid cells; bc_B / bc_D: physical face types [2 * dim + side] (FieldState::bc_names values).
+    Returns the new field on the valid cells."""
+    phys = {1: DIRICHLET, 2: NEUMANN, 3: NEUMANN}      # set_field_bcs (:93-119); 4 ('asymmetry') -> reflect_odd: refused
+    def faces(t):
+        out = []
+        for d in range(dim):
+            if periodic[d]:
+                out.append((PERIODIC, PERIODIC))
+            else:
+                if t[2 * d] not in phys or t[2 * d + 1] not in phys:
+                    raise NotImplementedError("divergence projection: faces must be inflow / outflow / symmetry")
+                out.append((phys[t[2 * d]], phys[t[2 * d + 1]]))
+        return out
+    one = tuple(slice(ng - 1, -(ng - 1) if ng > 1 else None) if (2 - ax) < dim else slice(None) for ax in range(3))
+    valid = tuple(slice(ng, -ng) if (2 - ax) < dim else slice(None) for ax in range(3))
+    F = np.array([Fg[c][valid] for c in range(10)])
+    Vb = np.array([Fg[3 + d][one] for d in range(dim)])
+    Vn, F[7] = solve_divergence_bc(Vb, dx, dim, faces(bc_B))
+    F[3:3 + dim] = Vn
+    cd = np.zeros_like(F[0])
+    for rho, r in zip(rhos, rs):
+        cd = cd + rho * r
+    S = (cd / F[9]) * (-cd_scale)
+    Vd = np.array([Fg[0 + d][one] for d in range(dim)])
+    Vn, F[6] = solve_divergence_bc(Vd, dx, dim, faces(bc_D), S)
+    F[0:dim] = Vn
+    return F
+
+
 def project_divergence_field(F, rhos, rs, dx, dim, cd_scale):
     """Elliptic::project_divergence_field (MFP_elliptic.cpp:667-782) on the field components F [10][k][j][i]."""
     F = F.copy()
@@ -216,8 +433,8 @@ class OracleSim:
         if lib().orc_error_flag():
             raise FloatingPointError("Primitive values outside of physical bounds!!")
         for fs, species in self.p.elliptic_actions():      # act->apply_change (MFP_advance.cpp:49)
-            if not all(self.p.periodic[:self.p.dim]):
-                raise NotImplementedError("divergence projection: periodic dimensions only")
+            if self.p.dim < 2:
+                continue                                   # MLNodeLaplacian not implemented for 1D (MFP_elliptic.cpp:640-650)
             r = self.p.ref
             gas = lambda s: self.p.cfg["states"][self.p.state_names[s]]["gas"]
 
@@ -226,9 +443,15 @@ class OracleSim:
                 U = self.get_state(s)
                 al = [U[5 + i] / U[0] for i in range(config.gas_n_tracers(gas(s)))]
                 return config.gas_charge_from_alpha(gas(s), al) / config.gas_mass_from_alpha(gas(s), al)
-            F = project_divergence_field(self.get_state(fs), [self.get_state(s)[0] for s in species],
-                                         [r_of(s) for s in species],
-                                         self.p.dx, self.p.dim, r["Larmor"] / (r["Debye"] ** 2 * r["lightspeed"]))
+            cd_scale = r["Larmor"] / (r["Debye"] ** 2 * r["lightspeed"])
+            if all(self.p.periodic[:self.p.dim]):
+                F = project_divergence_field(self.get_state(fs), [self.get_state(s)[0] for s in species],
+                                             [r_of(s) for s in species], self.p.dx, self.p.dim, cd_scale)
+            else:
+                bc_B, bc_D = self.p.elliptic_face_types(fs)
+                F = project_divergence_field_bc(self.fill_patch(fs), abi_ngrow(self.p, fs), [self.get_state(s)[0] for s in species],
+                                                [r_of(s) for s in species], self.p.dx, self.p.dim, cd_scale,
+                                                self.p.periodic, bc_B, bc_D)
             self.set_state(fs, F)
 
     def est_time_step(self):

@@ -1,9 +1,10 @@
 """bench.py's own N-rank code path under the driver's launcher, rehearsed on one GPU: the exact command line
 of the scaling run (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)
-with `--rehearse` (all ranks on cuda:0, gloo with host-staged halos, because RCCL refuses two ranks on one
-device).  Checks the JSON contract, that the collective backend saw N ranks, and that the split-block
-kernels (interior / frame launches, batched exchange, device-resident dt with the cross-rank minimum) ran.
-The RCCL transport itself (device buffers, N > 1) cannot run on a one-GPU box and stays unverified here."""
+with `--rehearse` (all ranks on cuda:0).  The transport bench.py selects first - the library's device-side
+transport over IPC-mapped arenas - runs here exactly as on the N-GPU node (one GPU instead of xGMI between the
+ranks); the gloo fallback is forced in two cases.  Checks the JSON contract, that the control group saw N ranks,
+and that the split-block kernels (interior / frame launches, device-resident dt with the cross-rank minimum) ran.
+RCCL from the callbacks (the second choice) cannot run with several ranks on a one-GPU box and stays unverified."""
 import json
 import os
 import socket
@@ -42,8 +43,10 @@ def _run(nranks, extra):
     # the rank count of the last leg of the scaling run (process grids 2 x 4 and 2 x 2 x 2)
     (8, ["--workload", "ot2f_2d", "--cells", "256", "--steps", "2", "--warmup", "1"], 256 * 256),
     (8, ["--workload", "rmi_3d", "--cells", "32", "--steps", "2", "--warmup", "1"], 32 ** 3),
-    # the transport bench.py falls back to when its RCCL pre-flight fails: everything through a second gloo group
+    # the transport bench.py falls back to when neither the device-side transport nor RCCL passes its pre-flight:
+    # halos and the dt word through host buffers over gloo, from the exchange callbacks
     (2, ["--workload", "ot2f_2d", "--cells", "256", "--steps", "2", "--warmup", "1", "--rehearse-fallback"], 256 * 256),
+    (4, ["--workload", "gem_2d", "--cells", "256", "--steps", "2", "--warmup", "1", "--transport", "gloo"], 256 * 128),
 ])
 def test_bench_n_rank_path(nranks, extra, cells):
     out = _run(nranks, extra)
@@ -60,8 +63,14 @@ def test_bench_n_rank_path(nranks, extra, cells):
     # value = cells of all ranks x steps / time of the median block
     assert abs(out["value"] - cells * nranks * steps / (out["ms_per_step"] * steps * 1e-3)) <= 1e-6 * out["value"]
     assert len(out["rep_ms_per_step"]) == 2 and out["ms_per_step"] > 0
-    assert out["host_ms_per_step"]["exchange"] > 0          # the exchange hook ran on the split block
     assert out["cpu_baseline"] is None                       # rank 0 at N = 1 only
-    assert out["halo_transport"].startswith("gloo")          # the rehearsal's transport (RCCL on the N-GPU node)
+    if "--rehearse-fallback" in extra or "gloo" in extra:
+        assert out["halo_transport"].startswith("gloo")
+        assert out["host_ms_per_step"]["exchange"] > 0      # the exchange hook ran on the split block
+    else:
+        # the default: the library's device-side transport (the same code runs over xGMI on the N-GPU node);
+        # no host code on the per-step path
+        assert out["halo_transport"].startswith("device-side")
+        assert out["host_ms_per_step"] == {"exchange": 0.0, "dt_reduce": 0.0}
     if out["config"]["workload"].startswith(("ot2f_2d", "gem_2d")):
         assert out["source_stages"] == {"A": "prologue of the CTU kernels", "C": "epilogue of the field kernel"}
