@@ -35,7 +35,7 @@ WORKLOAD_NOTE = {"ot2f_2d": "BASELINE configs[2]: 2D two-fluid Orszag-Tang, plas
                  "rmi_3d": "BASELINE configs[4]: 3D two-fluid Richtmyer-Meshkov, plasma5 source",
                  "gem_2d": "BASELINE configs[3]: 2D GEM reconnection two-fluid + Maxwell, walls in y; 8 GPUs x 4096x2048 = 8192^2"}
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r02"                         # profiles/<round>/pmc_<tag>.json: PMC traffic per launch of the kept profiles
+PROFILE_ROUND = "r03"                         # profiles/<round>/pmc_<tag>.json: PMC traffic per launch of the kept profiles
 PROFILE_TAG = {("ot2f_2d", 4096): "ot2f_4096", ("kh_2d", 2048): "kh_2048", ("gem_2d", 4096): "gem_4096", ("rmi_3d", 256): "rmi3d_256"}
 
 
@@ -149,7 +149,10 @@ def main():
     ap.add_argument("--tiled-hydro", action="store_true", help="diagnostic: LDS-tiled hydro CTU kernel instead of the wave-marching one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (profiling runs): no STRICT / other-workload legs, one timed block")
-    ap.add_argument("--extras-512", action="store_true", help="also RMI 512^3 (BASELINE configs[4] at full size; ~2 min of host-side set-up)")
+    ap.add_argument("--no-extras-512", action="store_true",
+                    help="skip the RMI 512^3 leg (BASELINE configs[4] at full size: 21.5 GB of state, about a minute of host-side set-up)")
+    ap.add_argument("--no-sustain", dest="sustain", action="store_false",
+                    help="skip the long block (>= 100 steps, >= 0.3 s) that is reported beside the K-step blocks")
     ap.add_argument("--rehearse", action="store_true",
                     help="diagnostic: run the N-rank path on ONE GPU (all ranks on cuda:0, gloo with host-staged halos); not a measurement")
     ap.add_argument("--rehearse-fallback", action="store_true",
@@ -258,18 +261,15 @@ def main():
     reps = 1 if args.no_extras else max(1, args.reps)
 
     def hbm_copy_gbs():
-        """attainable HBM bandwidth of this device: a 1 GiB device-to-device copy (read + write bytes)"""
-        a = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
-        b_ = torch.empty_like(a)
-        b_.copy_(a)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            b_.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        return 10 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        """attainable HBM bandwidth of this device: the library's copy probe (16 bytes per lane and access, read +
+        write bytes, best of three grid sizes; 1 GiB buffers: far beyond the 256 MB Infinity Cache)"""
+        import ctypes as C
+        from cerberus_amd import lib
+        v = C.c_double()
+        rc = lib.load().cmfp_hbm_copy_probe(local, None, 1 << 30, 10, C.byref(v))
+        if rc:
+            raise SystemExit(f"cmfp_hbm_copy_probe failed: {rc}")
+        return v.value
 
     def sync():
         torch.cuda.synchronize()
@@ -310,6 +310,20 @@ def main():
         prof = [m.profile_read(s) for s in range(4)]
         m.profile_enable(False)
         host = m.host_times()
+        # one long block beside the K-step blocks of the contract: at 3 ms per step K = 20 is a 0.06 s region; the
+        # sustained figure is one region of >= 100 steps and >= 0.3 s (no per-launch events in it)
+        sustained = None
+        if args.sustain and nrep > 1:
+            n_long = max(steps, 100, int(0.3 / max(1e-6, statistics.median(blocks) / steps)) + 1)
+            n_long = min(n_long, 4000)
+            sync()
+            t0 = time.perf_counter()
+            m.run(n_long)
+            sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sustained = {"steps": n_long, "seconds": float(t.item()), "ms_per_step": float(t.item()) / n_long * 1e3}
         m.close()
         el = statistics.median(blocks)
         tsteps = steps * nrep
@@ -327,6 +341,9 @@ def main():
                                  "C": "epilogue of the field kernel" if fusion & 2 else "own launch"},
                "workload": f"{workload} {'x'.join(str(v) for v in blk)} per GPU ({WORKLOAD_NOTE[workload]})",
                "process_grid": grid[:dim], "global_cells": list(P.n_cell[:dim]), "time_integration": P.scheme, "cfl": P.cfl}
+        if sustained:
+            sustained["value"] = cells * world * sustained["steps"] / sustained["seconds"]
+            res["sustained"] = sustained
         if world > 1:
             res["host_ms_per_step"] = {k: v / tsteps * 1e3 for k, v in host.items()}
         if rank != 0:
@@ -411,18 +428,20 @@ def main():
             "roofline": main_res["roofline"], "roofline_other": main_res["roofline_other"],
             "kernel_ms_per_step": main_res["kernel_ms_per_step"], "source_stages": main_res["source_stages"],
         }
+        if "sustained" in main_res:
+            out["sustained"] = main_res["sustained"]
         if "host_ms_per_step" in main_res:
             out["host_ms_per_step"] = main_res["host_ms_per_step"]
     # ---- extra legs: single GPU only (they are not part of the scaling contract)
     if world == 1 and not args.no_extras:
         keep = ("value", "ms_per_step", "rep_ms_per_step", "hbm_roofline_frac_whole_step", "kernel_ms_per_step", "roofline",
-                "roofline_other", "workload", "fp_mode", "source_stages")
+                "roofline_other", "workload", "fp_mode", "source_stages", "sustained")
         other_fp = "strict" if args.fp == "fast" else "fast"
         r = measure(args.workload, args.n, other_fp, max(5, args.steps // 2), 2, 3, copy_gbs)
         out[other_fp] = {k: r[k] for k in keep if k in r}
         others = {}
         legs = [("kh_2d", 2048, 40), ("gem_2d", 4096, 10), ("rmi_3d", 256, 5), ("ot2f_2d_implicit", 4096, 6)]
-        if args.extras_512:
+        if not args.no_extras_512:
             legs.append(("rmi_3d", 512, 3))
         for w, n, st in legs:
             if (w, n) == (args.workload, args.n):

@@ -1349,6 +1349,10 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
         c->touches[d][0] = on && !geom->is_periodic[d] && geom->block_lo[d] == 0;
         c->touches[d][1] = on && !geom->is_periodic[d] && geom->block_lo[d] + geom->block_n[d] == geom->n_cell[d];
     }
+    g.bc_instance = 0;
+    if (params->fp_mode == CMFP_FP_FAST)
+        for (int d = 0; d < geom->dim; ++d)
+            if (!geom->is_periodic[d]) g.bc_instance = 1;  // the same kernel instances on every rank of this domain (Geo)
     g.sj = g.ext[0];
     g.sk = (long)g.ext[0] * g.ext[1];
     g.sc = g.sk * g.ext[2];

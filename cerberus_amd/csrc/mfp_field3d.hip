@@ -401,7 +401,7 @@ static int launch_f3d(const Geo& g, const StatePhys& sp, const double* Uin, doub
     if (g.ng[0] < H + 1 || g.ng[1] < H + 1 || g.ng[2] < H + 1) return 0;
     if (!Uin) return 1;  // coverage probe
     FaceBC3f bc;
-    bool has_bc = false;
+    bool has_bc = g.bc_instance != 0;
     for (int d = 0; d < 3; ++d)
         for (int s = 0; s < 2; ++s) {
             bc.touch[d][s] = touches[d][s];

@@ -435,7 +435,7 @@ static int launch2d(const Geo& g, const typename Phys::Params& P, const StatePhy
     if (!Uin) return n_int > 0;  // split probe: is there an interior to overlap with?
     sel.n = part == 0 ? sel.gx * sel.gy : part == 1 ? n_int : sel.gx * sel.gy - n_int;
     if (sel.n <= 0) return 1;
-    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
+    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1] || g.bc_instance;
     const dim3 grid(((sel.n + 7) / 8) * 8), block(BX, BY);
     const FaceBC bc = make_bc(sp, touches);
 #define CMFP_LAUNCH(BC, RED) \
@@ -464,7 +464,7 @@ static int launch2d_src(const Geo& g, const typename Phys::Params& P, const Stat
     const int n_int = tile_interior<TX, TY, H>(g, sel);
     sel.n = part == 0 ? sel.gx * sel.gy : part == 1 ? n_int : sel.gx * sel.gy - n_int;
     if (sel.n <= 0) return 1;
-    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
+    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1] || g.bc_instance;
     const dim3 grid(((sel.n + 7) / 8) * 8), block(BX, BY);
     const FaceBC bc = make_bc(sp, touches);
     if (has_bc)

@@ -420,7 +420,7 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
     if (Uin[0] && !march_select(g, part & 0xff, 2, MW, n, sel)) return 1;
     sel.wrap = part_wrap(part);
     part &= 0xff;
-    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
+    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1] || g.bc_instance;
     if (pro) {  // the prologue: FAST build, both species in the launch, stage C follows (no reduction here)
 #ifdef CMFP_FASTMATH
         if (n != 2 || red[0]) return 0;

@@ -446,7 +446,7 @@ static int launch3d(const Geo& g, int ns, const StatePhys* const sps[2], const d
     sel.nseg = (g.n[2] + seg - 1) / seg;
     sel.n = tiles * sel.nseg;
     FaceBC3m bc;
-    bool has_bc = false;
+    bool has_bc = g.bc_instance != 0;
     for (int d = 0; d < 3; ++d)
         for (int s = 0; s < 2; ++s) {
             bc.touch[d][s] = touches[d][s];

@@ -403,7 +403,7 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
     if (off || g.dim != 2 || sp.kind != 1 || !do_ctu || sp.recon != 5 || sp.flux != 10 || !sp.vacuum || (part & 0xff) != 0) return 0;
     if (g.ng[0] < 4 || g.ng[1] < 4 || g.n[0] < 1 || g.n[1] < 1) return 0;
     if (epi && (epi->a.implicit || epi->a.coll.on || epi->ns < 1 || epi->ns > 2)) return 0;
-    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1];
+    const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1] || g.bc_instance;
     if (pro) {  // source stage A as the prologue: FAST build, two species with the epilogue
 #ifdef CMFP_FASTMATH
         if (!epi || epi->ns != 2) return 0;

@@ -703,7 +703,7 @@ int ctu_field3d_march(const Geo& g, const StatePhys& sp, const double* Uin, doub
     if (epi && (epi->a.implicit || epi->a.coll.on || epi->ns < 1 || epi->ns > 2)) return 0;
     f3m_pass1(g, sp, Uin, dF, dt, st);
     FaceBC3m bc;
-    bool has_bc = false;
+    bool has_bc = g.bc_instance != 0;
     for (int d = 0; d < 3; ++d)
         for (int s = 0; s < 2; ++s) {
             bc.touch[d][s] = touches[d][s];

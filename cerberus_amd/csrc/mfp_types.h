@@ -37,6 +37,10 @@ struct Geo {
     // (1 for the flux update, 1/2 for a source half step) of *dtp, read on the device, so that a
     // sequence of steps can be enqueued without the host knowing dt
     const double* dtp;
+    // 1: every launch takes the kernel instance that carries the domain-face rules, also on a block that touches no
+    // physical face.  Set in FAST arithmetic on a domain with a non-periodic direction: the compiler contracts the
+    // instances with and without the rules differently, and the ranks of a decomposed run must round alike.
+    int bc_instance;
     __host__ __device__ long at(int i, int j, int k) const {
         return (long)(i + ng[0]) + (long)(j + ng[1]) * sj + (long)(k + ng[2]) * sk;
     }

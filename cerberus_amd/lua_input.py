@@ -1202,9 +1202,10 @@ def problem_from_lua(interp, geometry, action_map=None):
             d["type"] = t = action_map[t]
             d = {k: v for k, v in d.items() if k in ("type", "states", "corner_transport", "solver", "cross_sections")}
             d.setdefault("corner_transport", True)
-        if t == "elliptic" and int(d.get("projection", 0)) == 1 and all(geometry["is_periodic"][:geometry["dim"]]) \
-                and geometry["dim"] > 1 and d.get("state") in states:
-            actions[name] = d        # divergence projection: built for periodic domains
+        if t == "elliptic" and int(d.get("projection", 0)) == 1 and d.get("state") in states:
+            # divergence projection (cmfp_elliptic_project_bc): periodic directions and outflow / symmetry / inflow
+            # faces; a no-op in 1-D as in the reference (MFP_elliptic.cpp:640-650)
+            actions[name] = d
             continue
         if t not in _ON_PATH_ACTIONS:
             ignored.append(f"actions.{name} (type '{t}')")

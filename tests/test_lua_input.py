@@ -75,8 +75,9 @@ def test_interpreter_subset():
     assert G.get("fmt") == "3- 2.50-x"
     assert lua_input.to_python(G.get("B"), it) == [0, 1.0, 0]
     assert it.call_value(G.get("sgn"), [-3.0]) == [-1] and it.call_value(G.get("pick"), [11.0, 5, 6]) == [-1]
-    assert sorted(cfg["states"]) == ["field", "ion"] and sorted(cfg["actions"]) == ["em", "fluxes", "lor"]
-    assert any("dust" in s for s in cfg["_ignored"]) and any("clean" in s for s in cfg["_ignored"])
+    # (the `elliptic` projection is kept since round 3: outflow faces in x, periodic in y - the Thermal-RMI domain)
+    assert sorted(cfg["states"]) == ["field", "ion"] and sorted(cfg["actions"]) == ["clean", "em", "fluxes", "lor"]
+    assert any("dust" in s for s in cfg["_ignored"]) and not any("clean" in s for s in cfg["_ignored"])
     assert any("refinement" in s for s in cfg["_ignored"])
     P = config.Problem(cfg)
     U = P.initial_data(P.state_index["ion"])
@@ -101,7 +102,7 @@ def test_parmparse_and_dofile(tmp_path):
     assert cfg["dim"] == 2 and cfg["n_cell"] == [64, 8] and cfg["prob_lo"] == [-4.0, 0.0] and cfg["is_periodic"] == [0, 1]
     assert cfg["cfl"] == 0.25 and info["stop_time"] == 0.3 and info["max_step"] == 1000
     P = config.Problem(cfg)
-    assert P.state_names == ["field", "ion"] and P.action_names == ["em", "fluxes", "lor"]
+    assert P.state_names == ["field", "ion"] and P.action_names == ["em", "fluxes", "lor"] and P.elliptic_names == ["clean"]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not present on this machine")
@@ -109,8 +110,9 @@ def test_reference_thermal_rmi_loads_unchanged(oracle):
     """Exec/testing/Thermal-RMI/TRMI.inputs + problem_definition.lua:1-323, as shipped"""
     cfg, info = lua_input.load_inputs(os.path.join(REF, "Thermal-RMI", "TRMI.inputs"), n_cell=[128, 16])
     assert sorted(cfg["states"]) == ["electron", "field", "ion"]
-    assert sorted(cfg["actions"]) == ["em_fluxes", "hydro_fluxes", "plasma"]
-    for dropped in ("electron_tracer", "ion_tracer", "divergence_cleaning", "tracer_electron", "tracer_ion"):
+    assert sorted(cfg["actions"]) == ["divergence_cleaning", "em_fluxes", "hydro_fluxes", "plasma"]
+    assert cfg["actions"]["divergence_cleaning"] == {"type": "elliptic", "projection": 1, "state": "field"}
+    for dropped in ("electron_tracer", "ion_tracer", "tracer_electron", "tracer_ion"):
         assert any(dropped in s for s in info["ignored"]), dropped
     ion, ele, fld = cfg["states"]["ion"], cfg["states"]["electron"], cfg["states"]["field"]
     assert ion["gas"] == {"type": "thermally_perfect", "mass": 1.0, "charge": 1, "gamma": 5 / 3}
