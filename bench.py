@@ -113,6 +113,9 @@ def cpu_baseline(workload, seconds=12.0):
         sim.advance(dt)
         s1 += 1
     out["one_core_value"] = n1 * n1 * s1 / (time.perf_counter() - t0)
+    # how well the port itself scales over the cores it was given (round 2: 4.4 x one core on 16 threads, the three
+    # FillPatch copies per state and step and the dt reductions were serial; threaded over the boxes since round 3)
+    out["parallel_efficiency"] = out["value"] / (threads * out["one_core_value"])
     O.lib().orc_set_threads(threads)
     return out
 

@@ -1424,7 +1424,10 @@ struct Sim {
         Box gb = grow(G.domain, ng, DIM);
         glob.resize(gb, S.n_cons);
         glob.setVal(std::numeric_limits<Real>::quiet_NaN());
-        for (size_t b = 0; b < boxes.size(); ++b) {
+        // (the copies of this function are threaded over the boxes since round 3: three FillPatch calls per state
+        // and step were the serial part that held the 16-thread baseline of bench.py to 4.4 x one core)
+#pragma omp parallel for schedule(static)
+        for (long b = 0; b < (long)boxes.size(); ++b) {
             const Box& bx = boxes[b];
             for (int n = 0; n < S.n_cons; ++n)
                 for (int k = bx.lo[2]; k <= bx.hi[2]; ++k)
@@ -1474,7 +1477,8 @@ struct Sim {
             }
         }
         U.resize(boxes.size());
-        for (size_t b = 0; b < boxes.size(); ++b) {
+#pragma omp parallel for schedule(static)
+        for (long b = 0; b < (long)boxes.size(); ++b) {
             Box ub = grow(boxes[b], ng, DIM);
             U[b].resize(ub, S.n_cons);
             for (int n = 0; n < S.n_cons; ++n)
@@ -1508,7 +1512,8 @@ struct Sim {
                         for (size_t b = 0; b < boxes.size(); ++b) ud.U[b].resize(boxes[b], ns);
                         ud.U_ng = 0;
                     }
-                    for (size_t b = 0; b < boxes.size(); ++b) {
+#pragma omp parallel for schedule(static)
+                    for (long b = 0; b < (long)boxes.size(); ++b) {
                         const Box& bx = boxes[b];
                         for (int n = 0; n < ns; ++n)
                             for (int k = bx.lo[2]; k <= bx.hi[2]; ++k)
@@ -2036,8 +2041,10 @@ struct Sim {
             return dt;
         }
         Real max_speed = std::numeric_limits<Real>::min();
-        Real U[CMFP_MAX_COMP], sp[3];
-        for (size_t b = 0; b < boxes.size(); ++b) {
+        // (a maximum / minimum is the same whatever the order: threaded over the boxes)
+#pragma omp parallel for schedule(static) reduction(max : max_speed)
+        for (long b = 0; b < (long)boxes.size(); ++b) {
+            Real U[CMFP_MAX_COMP], sp[3];
             const Box& bx = boxes[b];
             const Fab& data = new_data[s][b];
             for (int k = bx.lo[2]; k <= bx.hi[2]; ++k)
@@ -2054,6 +2061,7 @@ struct Sim {
             // HydroState::get_allowed_time_step MFP_hydro.cpp:726-736 with HydroViscous::get_min_dt
             // (MFP_hydro_viscous.cpp:34-97): max over cells starts from 0
             Real vmax = 0;
+            Real U[CMFP_MAX_COMP];
             for (size_t b = 0; b < boxes.size(); ++b) {
                 const Box& bx = boxes[b];
                 const Fab& data = new_data[s][b];
@@ -2087,7 +2095,8 @@ struct Sim {
         max_speed = std::max(max_speed, field.div_speed);
         Real dt = G.dx[0] / max_speed;
         for (int d = 1; d < DIM; ++d) dt = std::min(dt, G.dx[d] / max_speed);
-        for (size_t b = 0; b < boxes.size(); ++b) {
+#pragma omp parallel for schedule(static) reduction(min : dt)
+        for (long b = 0; b < (long)boxes.size(); ++b) {
             const Box& bx = boxes[b];
             const Fab& field4 = new_data[fs][b];
             for (int k = bx.lo[2]; k <= bx.hi[2]; ++k)
