@@ -531,12 +531,62 @@ def lua_tostring(v):
     return f"{lua_type(v)}: 0x{id(v):x}"
 
 
+# What MFP::set_lua_script puts in front of the user's script (MFP_config.cpp:14-21 prepends Source/default.lua): the
+# utility functions of default.lua:117-250 a problem definition may call or override - same names and results,
+# written here for this interpreter (get_args / get_num_args need Lua's debug library and are left out) - and the
+# empty preprocess() hook that load_inputs / load_lua call after the script, as the reference appends "preprocess()".
+PRELUDE = r"""
+function spairs(t, order)
+  local keys = {}
+  for k in pairs(t) do keys[#keys + 1] = k end
+  if order then table.sort(keys, function(a, b) return order(t, a, b) end) else table.sort(keys) end
+  local i = 0
+  return function()
+    i = i + 1
+    if keys[i] then return keys[i], t[keys[i]] end
+  end
+end
+function len(T)
+  local n = 0
+  for _ in pairs(T) do n = n + 1 end
+  return n
+end
+function get_sorted_keys(T)
+  local keys = {}
+  local n = 0
+  for k, v in spairs(T) do n = n + 1; keys[n] = k end
+  return keys
+end
+function expand(v, opt)
+  if type(v) ~= 'table' then return { v, v or opt } end
+  return v
+end
+function exists(v) if not v then return 0 end return 1 end
+function is_function(v) if type(v) == 'function' then return 1 end return 0 end
+function is_table(v) if type(v) == 'table' then return 1 end return 0 end
+function get_ipairs(v)
+  local out = {}
+  for _, value in ipairs(v) do table.insert(out, value) end
+  return out
+end
+function preprocess() end
+"""
+
+
 class Interpreter:
     def __init__(self, base_dir="."):
         self.base_dir = base_dir
         self.globals = LuaTable()
         self.output = []
         self._install_stdlib()
+        self.run(PRELUDE)
+
+    def run_user_script(self, src):
+        """the user's script followed by preprocess() (MFP_config.cpp:14-21)"""
+        self.run(src)
+        hook = self.globals.get("preprocess")
+        if hook is not None:
+            self.call_value(hook, [])
 
     # -- library ----------------------------------------------------------------------------------
     def _install_stdlib(self):
@@ -1141,9 +1191,57 @@ def wrap_function(fn, interp):
             of[i] = r[0]
         return out
     call.lua_function = fn
-    # a function whose text mentions the key 't' may depend on time: its boundary tables are refreshed every step
-    call.uses_time = _mentions(fn.body, "t") if isinstance(fn, LuaFunction) else True
+    # A function may depend on time if its own text mentions the key 't' - or if a function it calls does (a helper or
+    # an upvalue can reach dat.t out of sight): called Lua functions are followed through the closure's scopes and the
+    # globals; a callee that cannot be resolved to a Lua function or a library member counts as time dependent.  Its
+    # boundary tables are then refreshed every step: erring on that side costs a re-tabulation, the other side leaves
+    # boundary data stale.
+    call.uses_time = _may_use_time(fn, interp, set()) if isinstance(fn, LuaFunction) else True
     return call
+
+
+_LIBRARY_TABLES = ("math", "string", "table")
+
+
+def _callees(node, out):
+    if isinstance(node, tuple):
+        if node and node[0] in ("call", "method"):
+            out.append(node)
+        for x in node:
+            _callees(x, out)
+    elif isinstance(node, list):
+        for x in node:
+            _callees(x, out)
+
+
+def _may_use_time(fn, interp, seen):
+    if id(fn) in seen:
+        return False
+    seen.add(id(fn))
+    if _mentions(fn.body, "t"):
+        return True
+    calls = []
+    _callees(fn.body, calls)
+    for c in calls:
+        if c[0] == "method":
+            return True                                   # obj:method(...): not followed
+        callee = c[1]
+        if isinstance(callee, tuple) and callee[0] == "index" and isinstance(callee[1], tuple) and callee[1][0] == "name" \
+                and callee[1][1] in _LIBRARY_TABLES:
+            continue                                      # math.* / string.* / table.* members
+        if not (isinstance(callee, tuple) and callee[0] == "name"):
+            return True
+        name = callee[1]
+        sc = fn.env.find(name) if isinstance(fn.env, Scope) else None
+        target = sc.vars[name] if sc is not None else interp.globals.get(name)
+        if isinstance(target, LuaFunction):
+            if _may_use_time(target, interp, seen):
+                return True
+        elif callable(target) and name in ("tostring", "tonumber", "type", "ipairs", "pairs", "select", "print", "assert", "error"):
+            continue
+        else:
+            return True                                   # a parameter, a table member, nil: unknown at this point
+    return False
 
 
 def _mentions(node, key):
@@ -1249,7 +1347,7 @@ def load_inputs(path, n_cell=None, action_map=None, max_level0_only=True):
     script = "\n".join(pp.get("mfp.lua", []))
     if not script.strip():
         raise ValueError("inputs file has no mfp.lua script")
-    interp.run(script)
+    interp.run_user_script(script)
     cfg = problem_from_lua(interp, geometry, action_map)
     info = {"stop_time": nums("stop_time", [-1.0])[0], "max_step": int(nums("max_step", [-1.0])[0]),
             "ignored": cfg["_ignored"], "output": interp.output, "interpreter": interp}
@@ -1259,5 +1357,5 @@ def load_inputs(path, n_cell=None, action_map=None, max_level0_only=True):
 def load_lua(text, geometry, base_dir=".", action_map=None):
     """The same for a Lua script given as text."""
     interp = Interpreter(base_dir)
-    interp.run(text)
+    interp.run_user_script(text)
     return problem_from_lua(interp, geometry, action_map), interp

@@ -92,6 +92,35 @@ def test_interpreter_subset():
         lua_input.load_lua("states = { a = { type='hydro' } } actions = { f = { type='CTU', states={'b'} } }", dict(GEOM))
 
 
+def test_default_lua_prelude_and_preprocess_hook():
+    """MFP::set_lua_script (MFP_config.cpp:14-21) runs default.lua before the user's script and preprocess() after
+    it: the utilities of default.lua:117-250 exist (and may be overridden), the hook is called, and a boundary
+    function that reaches dat.t through a helper counts as time dependent (its tables are refreshed every step)."""
+    script = SCRIPT + r"""
+keys = get_sorted_keys({ b = 1, a = 2, c = 3 })
+nk = len({ x = 1, y = 2, 5 })
+ex = expand(4)
+flags = { exists(nil), exists(0), is_function(print), is_function(3), is_table({}), is_table('t') }
+ip = get_ipairs({ 7, 8, k = 9 })
+order = {}
+for k, v in spairs({ z = 1, m = 2 }, function(t, a, b) return t[a] > t[b] end) do order[#order + 1] = k end
+called = 0
+function preprocess() called = called + 1; cfl = 0.125 end
+local function ramp(dat) return dat.t * 2 end
+states.ion.bc = { x = { lo = { fill_hydro_bc = 'inflow', rho = function(dat) return 1 + ramp(dat) end, x_vel = 0.5,
+                               y_vel = 0, z_vel = 0, p = function(dat) return 1 + math.sin(dat.x) end, T = 1, gamma = 1, cp = 1 } } }
+"""
+    cfg, it = lua_input.load_lua(script, dict(GEOM))
+    G = it.globals
+    tp = lambda n: lua_input.to_python(G.get(n), it)
+    assert tp("keys") == ["a", "b", "c"] and G.get("nk") == 3 and tp("ex") == [4, 4]
+    assert tp("flags") == [0, 1, 1, 0, 1, 0] and tp("ip") == [7, 8] and tp("order") == ["m", "z"]
+    assert G.get("called") == 1 and cfg["cfl"] == 0.125            # preprocess() ran after the script, before the read-out
+    lo = cfg["states"]["ion"]["bc"]["x"]["lo"]
+    assert lo["rho"].uses_time is True                             # dat.t only inside the helper
+    assert lo["p"].uses_time is False                              # math.* calls alone do not make it time dependent
+
+
 def test_parmparse_and_dofile(tmp_path):
     (tmp_path / "problem.lua").write_text(SCRIPT)
     (tmp_path / "case.inputs").write_text(
