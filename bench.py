@@ -209,6 +209,10 @@ def main():
         #    failure on any rank (IPC refused, a device-side wait that times out) selects the next transport.
         if want in ("auto", "peer"):
             ok = True
+            # a partner that never arrives is given up after CMFP_PEER_TIMEOUT seconds per wait: short for the
+            # pre-flight (a failed transport then costs seconds, not minutes), the library's default for the run
+            old_to = os.environ.get("CMFP_PEER_TIMEOUT")
+            os.environ["CMFP_PEER_TIMEOUT"] = "5"
             try:
                 P0 = build_problem("ot2f_2d", 64, block_grid(2, world), abi.FP_FAST)
                 m0 = MFP(P0, device=local, rank=rank, world=world, stream=0, exchange_device="cpu", transport="peer")
@@ -220,6 +224,11 @@ def main():
             except Exception as e:       # noqa: BLE001 - any failure of this transport selects the next one
                 print(f"[bench rank {rank}] device-side (IPC) transport pre-flight failed: {e!r}", file=sys.stderr, flush=True)
                 ok = False
+            finally:
+                if old_to is None:
+                    os.environ.pop("CMFP_PEER_TIMEOUT", None)
+                else:
+                    os.environ["CMFP_PEER_TIMEOUT"] = old_to
             if agree(ok):
                 kind, transport = "peer", "device-side: IPC-mapped arenas, pack kernels write into the neighbour's slot (cmfp_peer_*)"
                 if args.rehearse:
