@@ -109,6 +109,9 @@ class MFP:
             raise lib.CmfpError(rc, self.L.cmfp_last_error(self.h).decode())
 
     def close(self):
+        if getattr(self, "_proj", None) is not None:
+            self._proj.close()
+            self._proj = None
         if getattr(self, "h", None):
             self.L.cmfp_destroy(self.h)
             self.h = None
@@ -177,11 +180,49 @@ class MFP:
             self._upload_face_values(s, self.time + dt)
         self._chk(self.L.cmfp_advance(self.h, self.time, dt))
         for fs, species in self._elliptic:     # act->apply_change (MFP_advance.cpp:49)
+            if self.world > 1 and self.p.dim > 1:
+                self._project_gathered(fs, species)
+                continue
             arr = (C.c_int * max(1, len(species)))(*species)
             bc_B, bc_D = self.p.elliptic_face_types(fs)
             self._chk(self.L.cmfp_elliptic_project_bc(self.h, fs, len(species), arr, (C.c_int * 6)(*bc_B), (C.c_int * 6)(*bc_D)))
         self.time += dt
         self.step += 1
+
+    def _project_gathered(self, fs, species):
+        """The divergence projection on a domain that is split between ranks.  The solve is global (a node Laplacian
+        over the whole level; the reference hands it to AMReX's MLMG, which communicates inside every V-cycle).  Here
+        the blocks of the field and of the species are gathered to EVERY rank, each rank runs the single-block
+        projection of the library on the whole level - a second, whole-level context on its own GPU - and keeps its
+        own block of the result: the same arithmetic as the single-rank run (bit-identical results), N times the
+        work, and one all-gather of the field (10 components) and the species per step over the host's collective.
+        Functional, not fast: no BASELINE configuration carries an `elliptic` action."""
+        import torch
+        import torch.distributed as dist
+        backend = dist.get_backend(self.pg)
+        dev = "cpu" if backend == "gloo" else self._pack_device()
+        if getattr(self, "_proj", None) is None:
+            self._proj = MFP(self.p, device=int(torch.cuda.current_device()), rank=0, world=1, stream=self._stream)
+        g = self._proj
+        lo, n = self.block_lo, self.block_n
+
+        def gather_into(s):
+            mine = torch.from_numpy(np.ascontiguousarray(self.download(s))).to(dev)
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.pg)
+            full = np.empty((self.p.n_comp(s),) + tuple(self.p.n_cell[::-1]))
+            for r, part in enumerate(parts):
+                c = rank_coords(r, self.grid)
+                o = [c[d] * self.block_n[d] for d in range(3)]
+                full[:, o[2]:o[2] + n[2], o[1]:o[1] + n[1], o[0]:o[0] + n[0]] = part.cpu().numpy()
+            g.upload(s, full)
+        for s in [fs] + list(species):
+            gather_into(s)
+        arr = (C.c_int * max(1, len(species)))(*species)
+        bc_B, bc_D = self.p.elliptic_face_types(fs)
+        g._chk(g.L.cmfp_elliptic_project_bc(g.h, fs, len(species), arr, (C.c_int * 6)(*bc_B), (C.c_int * 6)(*bc_D)))
+        F = g.download(fs)
+        self.upload(fs, F[:, lo[2]:lo[2] + n[2], lo[1]:lo[1] + n[1], lo[0]:lo[0] + n[0]])
 
     def est_time_step(self):
         """MFP::estTimeStep incl. ParallelDescriptor::ReduceRealMin (MFP_timestep.cpp:4-21)."""
@@ -313,6 +354,10 @@ class MFP:
         import torch
         if self._exchange_device is not None:
             return self._exchange_device
+        if self.world > 1:
+            import torch.distributed as dist
+            if dist.get_backend(self.pg) == "gloo":       # the control group of a run on the device-side transport
+                return torch.device("cpu")
         return torch.device("cuda", torch.cuda.current_device())
 
     def neighbour(self, d, side):

@@ -64,6 +64,15 @@ def _cfg(which):
         cfg = problems.orszag_tang_two_fluid_2d(32)
         return problems.with_mixture(cfg, "ion", [lambda d: 0.5 + 0.3 * np.sin(d["x"]) * np.cos(d["y"])], [1.0, 3.0],
                                      [5 / 3, 1.4], [1.0, 2.0])
+    if which == "trmi":         # the reference's shipped Thermal-RMI input (tests/golden tree, 64 x 8) with its `elliptic` projection
+        import json
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from make_trmi_fixture import OUT, problem_cfg
+        return problem_cfg(json.load(open(OUT)))
+    if which == "otclean":      # periodic two-fluid problem with the projection after every step
+        cfg = problems.orszag_tang_two_fluid_2d(32)
+        cfg["actions"]["divergence_cleaning"] = {"type": "elliptic", "projection": 1, "state": "field"}
+        return cfg
     if which == "gem":
         return problems.gem_reconnection_2d(32, 32)
     if which == "gem64":        # 2 x 4 blocks of 32 x 16 with the conducting walls on the outer ranks in y
@@ -111,7 +120,10 @@ def test_decomposed_run_equals_single_rank(world, which, batched):
                                                  (4, "ot512", True), (8, "ot512", True), (8, "gem64", True),
                                                  (4, "rmi3d", True), (8, "rmi3d24", True), (4, "inflow", True),
                                                  (4, "ot512@fast", True), (8, "ot512@fast", True), (8, "gem64@fast", True),
-                                                 (4, "rmi3d24@fast", True), (4, "mix2d", True), (4, "rand1", True), (2, "rand4", False)])
+                                                 (4, "rmi3d24@fast", True), (4, "mix2d", True), (4, "rand1", True), (2, "rand4", False),
+                                                 # the divergence projection on a split domain: blocks gathered to every rank,
+                                                 # whole-level solve on each (MFP._project_gathered): the single-rank bits
+                                                 (2, "trmi", True), (4, "otclean", True), (4, "otclean@fast", True)])
 def test_decomposed_run_on_the_peer_transport(world, which, batched):
     _decomposed(world, which, batched, "peer")
 
@@ -152,7 +164,8 @@ def _decomposed(world, which, batched, transport):
             assert o["host_t"] == {"exchange": 0.0, "dt_reduce": 0.0}, "the hooks must not run with the device-side transport"
         if not which.startswith(("rand", "mix")):
             assert o["fused"]           # (since round 2 also the inflow case: marching kernel with the face tables)
-            assert o["device_dt"]     # cmfp_advance_steps with the cross-rank dt minimum on the device
+            # cmfp_advance_steps with the cross-rank dt minimum on the device (an `elliptic` action runs between steps: per-step driver)
+            assert o["device_dt"] == (not which.startswith(("trmi", "otclean")))
         lo, n = o["lo"], o["n"]
         for s in range(len(full)):
             ref = full[s][:, lo[2]:lo[2] + n[2], lo[1]:lo[1] + n[1], lo[0]:lo[0] + n[0]]

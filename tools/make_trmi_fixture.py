@@ -50,11 +50,28 @@ def tree_of(path=SRC):
 
 def problem_cfg(tree):
     """the dict config.Problem takes, rebuilt from the tree (arrays become functions of the cell-centre dict that
-    return them: the tree holds the whole level, so only whole-level evaluation is meaningful)"""
+    return the part of the whole-level array at the centres asked for)"""
+    dim = int(tree["dim"])
+    lo = [float(v) for v in tree["prob_lo"]]
+    dx = [(float(tree["prob_hi"][d]) - lo[d]) / int(tree["n_cell"][d]) for d in range(dim)]
+
+    def block_of(arr, d):
+        """the part of the whole-level array at the cell centres asked for (a rank's block: located by its first centre)"""
+        shape = d["x"].shape
+        sl = [slice(None)] * 3
+        for ax, key in ((2, "x"), (1, "y"), (0, "z")):
+            e = 2 - ax
+            if e >= dim:
+                continue
+            first = float(np.asarray(d[key]).reshape(-1)[0])
+            i0 = int(round((first - lo[e]) / dx[e] - 0.5))
+            sl[ax] = slice(i0, i0 + shape[ax])
+        return arr[tuple(sl)]
+
     def live(v):
         if isinstance(v, dict) and "__array__" in v:
             arr = np.asarray(v["__array__"], dtype=np.float64)
-            return lambda d, arr=arr: arr
+            return lambda d, arr=arr: block_of(arr, d)
         if isinstance(v, dict):
             return {k: live(x) for k, x in v.items()}
         if isinstance(v, list):

@@ -1,5 +1,5 @@
 // valu_rate_probe.hip — issue cost of the fp64 instructions the marching kernels are made of (diagnostic, not part
-// of the library): cycles per wave-instruction on one SIMD with 1 and 2 waves resident, for independent chains of
+// of the library): cycles per wave-instruction on one SIMD with 1 and 2 waves resident, for 8 / 16 / 32 independent chains of
 // v_fma_f64, v_mul_f64, v_add_f64, v_rcp_f64, v_rsq_f64, v_rcp_f32 (+ conversions), v_cndmask pairs, v_mov_dpp pairs.
 //   hipcc --offload-arch=gfx950 -O3 tools/valu_rate_probe.hip -o tools/bin/valu_rate_probe && tools/bin/valu_rate_probe
 #include <hip/hip_runtime.h>
@@ -16,9 +16,9 @@
         }                                                                      \
     } while (0)
 
-constexpr int NACC = 8, ITER = 4096;
+constexpr int ITER = 4096;
 
-template <int OP>
+template <int OP, int NACC>
 __global__ __launch_bounds__(64) void k_probe(double* out, double seed) {
     double a[NACC];
 #pragma unroll
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void k_probe(double* out, double seed) {
     out[blockIdx.x * 64 + threadIdx.x] = s;
 }
 
-template <int OP>
+template <int OP, int NACC = 8>
 int run(const char* name, double instr_per_op, double* d_out) {
     int dev = 0;
     hipDeviceProp_t p;
@@ -62,9 +62,9 @@ int run(const char* name, double instr_per_op, double* d_out) {
     CHK(hipEventCreate(&e1));
     for (int waves_per_simd = 1; waves_per_simd <= 2; ++waves_per_simd) {
         const int grid = simds * waves_per_simd;
-        hipLaunchKernelGGL(k_probe<OP>, dim3(grid), dim3(64), 0, 0, d_out, 1.25);
+        hipLaunchKernelGGL((k_probe<OP, NACC>), dim3(grid), dim3(64), 0, 0, d_out, 1.25);
         CHK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_probe<OP>, dim3(grid), dim3(64), 0, 0, d_out, 1.25);
+        hipLaunchKernelGGL((k_probe<OP, NACC>), dim3(grid), dim3(64), 0, 0, d_out, 1.25);
         CHK(hipEventRecord(e1, 0));
         CHK(hipEventSynchronize(e1));
         float ms = 0;
@@ -72,7 +72,7 @@ int run(const char* name, double instr_per_op, double* d_out) {
         const double clk = (double)p.clockRate * 1e3;  // Hz
         const double ops_per_simd = (double)ITER * NACC * waves_per_simd;
         const double cyc = ms * 1e-3 * clk / ops_per_simd;
-        printf("%-28s waves/SIMD %d: %7.2f cycles per op (%4.1f instr) at %.0f MHz, %.3f ms\n", name, waves_per_simd, cyc, instr_per_op, clk / 1e6, ms);
+        printf("%-28s chains %2d waves/SIMD %d: %7.2f cycles per op (%4.1f instr) at %.0f MHz, %.3f ms\n", name, NACC, waves_per_simd, cyc, instr_per_op, clk / 1e6, ms);
     }
     return 0;
 }
@@ -81,6 +81,13 @@ int main() {
     double* d_out = nullptr;
     CHK(hipMalloc((void**)&d_out, sizeof(double) * 64 * 8192));
     run<0>("v_fma_f64", 1, d_out);
+    run<0, 16>("v_fma_f64", 1, d_out);
+    run<0, 32>("v_fma_f64", 1, d_out);
+    run<1, 16>("v_mul_f64", 1, d_out);
+    run<2, 32>("v_add_f64", 1, d_out);
+    run<3, 16>("v_rcp_f64", 1, d_out);
+    run<7, 16>("2 v_mov_b32 dpp wave_shr", 2, d_out);
+    run<6, 16>("v_cmp_f64 + 2 v_cndmask", 3, d_out);
     run<1>("v_mul_f64", 1, d_out);
     run<2>("v_add_f64", 1, d_out);
     run<8>("v_max_f64", 1, d_out);
