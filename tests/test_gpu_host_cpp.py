@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", [[], ["batch"], ["elliptic"], ["mixture"]],
-                         ids=["per_step", "advance_steps", "elliptic_action", "mixture_ions"])
+@pytest.mark.parametrize("mode", [[], ["batch"], ["elliptic"], ["mixture"], ["ranks"]],
+                         ids=["per_step", "advance_steps", "elliptic_action", "mixture_ions", "two_ranks_peer_transport"])
 def test_cpp_host_demo_matches_python_driver(mode):
     from cerberus_amd.mfp import MFP
     exe = os.path.join(ROOT, "cerberus_amd", "host", "host_demo")
@@ -22,6 +22,8 @@ def test_cpp_host_demo_matches_python_driver(mode):
     assert out.returncode == 0, out.stderr
     dts = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("dt ")]
     sums = {l.split()[1]: (float(l.split()[3]), float(l.split()[5])) for l in out.stdout.splitlines() if l.startswith("state ")}
+    # ["ranks"]: the level cut into two blocks, one context + host thread each, MFP::attach_local_peers (arenas by
+    # pointer): the STRICT build is decomposition-independent, so the single-rank run below is the expectation
     cfg = problems.orszag_tang_two_fluid_2d(32)
     if mode == ["elliptic"]:   # the mirror's Elliptic class (apply_change after every step, MFP_advance.cpp:49)
         cfg["actions"]["divergence_cleaning"] = {"type": "elliptic", "projection": 1, "state": "field"}
