@@ -89,4 +89,5 @@ class ActionDesc(C.Structure):
         ("n_states", C.c_int),
         ("states", C.c_int * MAX_ACTION_STATES),
         ("cross_sections", (C.c_double * MAX_ACTION_STATES) * MAX_ACTION_STATES),
+        ("species_component", C.c_int * MAX_ACTION_STATES),
     ]

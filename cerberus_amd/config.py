@@ -79,6 +79,16 @@ def gas_is_mixture(gas):
     return any(x != v[0] for v in (gas_list(gas, "mass"), gas_list(gas, "gamma"), gas_list(gas, "charge")) for x in v)
 
 
+def gas_comp_names(gas, state_name):
+    """Names of the sub-components of a gas: gas.names, else the state's name (one species) or <state>_<i>
+    (ThermallyPerfectGas, MFP_thermally_perfect_gas.cpp:27,42-48)."""
+    names = gas.get("names")
+    if names:
+        return [names] if isinstance(names, str) else list(names)
+    n = gas_n_tracers(gas) + 1
+    return [state_name] if n == 1 else [f"{state_name}_{i}" for i in range(n)]
+
+
 def gas_scalar(gas, key):
     """mass / charge / gamma of species 0: the constants of the gas where every species has the same
     (mass_const, charge_const, gamma_const, MFP_thermally_perfect_gas.cpp:33-35: the tracers are then
@@ -286,22 +296,45 @@ class Problem:
             if ad["type"] == "collisions_rambo":
                 if any(self.cfg["states"][n]["type"] != "hydro" for n in names):
                     raise ValueError(f"An invalid state has been defined for the Collisions source {name}")
+                # the species of the action: 'species' (names of gas sub-components), else the states themselves
+                # (init_species_info MFP_collisions.cpp:65-83); each is looked up in the states' gas.names (:43-60)
+                species = list(ad.get("species") or names)
+                where = []
+                for sn in species:
+                    hit = None
+                    for si, stn in enumerate(names):
+                        comps = gas_comp_names(self.cfg["states"][stn]["gas"], stn)
+                        if sn in comps:
+                            hit = (si, comps.index(sn))
+                            break
+                    if hit is None:
+                        raise ValueError(f"Couldn't find sub-component for '{sn}'")
+                    where.append(hit)
+                # the reference reads U, Q, alpha and the gas of species n from entry n of its state list
+                # (MFP_collisions.cpp:181-190): defined only where species n lives in state n
+                if [w[0] for w in where] != list(range(len(names))):
+                    raise NotImplementedError(
+                        f"action '{name}': species n must be a sub-component of state n of the 'states' list (the reference "
+                        "indexes the states' data with the species index, MFP_collisions.cpp:181-190)")
+                for n, (si, k) in enumerate(where):
+                    a.species_component[n] = k
+                charges = [gas_list(self.cfg["states"][names[si]]["gas"], "charge")[k] for si, k in where]
                 # cross_sections = {a = {b = sigma}}: non-dimensionalised and cross-loaded
                 # (MFP_collisions_rambo.cpp:39-55); names that are not species of this action are skipped
                 for na, row in ad.get("cross_sections", {}).items():
-                    if na not in names:
+                    if na not in species:
                         continue
                     for nb, sigma in row.items():
-                        if nb not in names:
+                        if nb not in species:
                             continue
-                        ia, ib = names.index(na), names.index(nb)
+                        ia, ib = species.index(na), species.index(nb)
                         s = float(sigma) / (self.ref["x_ref"] * self.ref["x_ref"])
                         a.cross_sections[ia][ib] = s
                         a.cross_sections[ib][ia] = s
                 if not ad.get("cross_sections"):
-                    for n in names:
-                        if gas_scalar(self.cfg["states"][n]["gas"], "charge") == 0.0:
-                            raise ValueError(f"cross sections for collisions involving neutral species '{n}' are "
+                    for sn, q in zip(species, charges):
+                        if q == 0.0:
+                            raise ValueError(f"cross sections for collisions involving neutral species '{sn}' are "
                                              f"required by action '{name}'")
             a.n_states = len(idx)
             for j, v in enumerate(idx):
@@ -398,6 +431,33 @@ class Problem:
 
     def face_values_depend_on_time(self, s):
         return any(getattr(v, "uses_time", False) for vals in self.face_entries(s).values() for v in vals.values())
+
+    # -- 'dynamic' components ------------------------------------------------
+    def dynamic_entries(self, s):
+        """{conserved component: its `value` entry} of states.<name>.dynamic = {'x_B', ...}: FieldState::set_udf
+        (MFP_field.cpp:175-221) points dynamic_functions[i] at the initialisation function of every listed
+        component.  HydroState::set_udf does not read the key: ignored there, as in the reference."""
+        sd = self.cfg["states"][self.state_names[s]]
+        if sd["type"] != "field":
+            return {}
+        names = sd.get("dynamic") or []
+        names = [names] if isinstance(names, str) else list(names)
+        val = sd.get("value", {})
+        return {c: val.get(n, FIELD_DEFAULT.get(n, 0.0)) for c, n in enumerate(FIELD_CONS) if n in names}
+
+    def dynamic_depends_on_time(self, s):
+        return any(getattr(v, "uses_time", False) for v in self.dynamic_entries(s).values())
+
+    def dynamic_tables(self, s, ng, t, block_lo=None, block_n=None):
+        """[(component, values)]: the functions at the centres of the block's cells and of ng ghost layers around
+        it (calc_primitives runs over grow(box, num_grow): x = prob_lo + (i + 0.5) dx, MFP_eulerian.cpp:349-355)."""
+        lo = [0, 0, 0] if block_lo is None else list(block_lo)
+        n = list(self.n_cell) if block_n is None else list(block_n)
+        glo = [lo[d] - ng if d < self.dim else 0 for d in range(3)]
+        gn = [n[d] + 2 * ng if d < self.dim else 1 for d in range(3)]
+        dat = self.cell_centres(glo, gn)
+        dat["t"] = t
+        return [(c, np.ascontiguousarray(self._eval(v, dat, dat["x"].shape))) for c, v in self.dynamic_entries(s).items()]
 
     # -- initial data ----------------------------------------------------
     def cell_centres(self, lo=None, n=None):

@@ -61,6 +61,8 @@ struct StateRT {
     double* tab_cell[3][2][CMFP_MAX_COMP] = {};
     double* tab_face[3][2][CMFP_MAX_COMP] = {};
     bool has_tables = false;
+    double* dyn[CMFP_MAX_COMP] = {};  // 'dynamic' components (cmfp_state_set_dynamic): values over the ghosted block
+    bool has_dynamic = false;
     // field: the materials check (mu == ep == 1 everywhere) has been made for the data now in new_data;
     // the ping-pong partner holds mu, ep too (the vacuum kernel neither reads nor rewrites them)
     bool vac_known = false, alt_mat = false;
@@ -520,7 +522,23 @@ int action_calc_time_derivative(cmfp_context* c, int ai, double dt) {
             s.dU_status = Changed;
         }
         a.coll = coll_args(c, A);
-        c->L->collisions(c->g, a, dt, c->stream);
+        bool sub = false;  // a state with sub-components: the reference's accounting over alpha (:218-257)
+        for (int n = 0; n < A.n_states; ++n) sub = sub || c->states[A.states[n]].desc.n_tracers > 0;
+        if (sub) {
+            CollMix cm;
+            std::memset(&cm, 0, sizeof(cm));
+            for (int n = 0; n < A.n_states; ++n) {
+                const StateRT& s = c->states[A.states[n]];
+                const int k = A.species_component[n];
+                cm.comp[n] = k;
+                cm.m[n] = s.desc.mixture ? s.desc.species_mass[k] : s.desc.mass;
+                cm.q[n] = s.desc.mixture ? s.desc.species_charge[k] : s.desc.charge;
+                cm.hp[n] = s.sp.hp;
+            }
+            c->L->collisions_mix(c->g, a, cm, dt, c->stream);
+        } else {
+            c->L->collisions(c->g, a, dt, c->stream);
+        }
         return CMFP_OK;
     }
     SourceArgs a = source_args(c, A, false);
@@ -593,6 +611,12 @@ int ctu_staged(cmfp_context* c, const cmfp_action_desc& A, double dt) {
         Ptr3 rlo{{s.rlo[0], s.rlo[1], s.rlo[2]}}, rhi{{s.rhi[0], s.rhi[1], s.rhi[2]}};
         Ptr3 fl{{s.flux[0], s.flux[1], s.flux[2]}};
         c->L->prim(g, s.sp, s.U, s.prim, c->d_err, c->stream);                       // :182
+        if (s.has_dynamic)  // MFP_eulerian.cpp:403-423: Q[n] = f(x, y, z, t), prim2cons back into the action's copy of U
+            for (int n = 0; n < s.sp.nc; ++n)
+                if (s.dyn[n]) {
+                    c->L->copy(g, 1, s.prim + n * g.sc, s.dyn[n], 1, c->stream);
+                    c->L->copy(g, 1, s.U + n * g.sc, s.dyn[n], 1, c->stream);
+                }
         if (s.has_tables) apply_cell_tables(c, s);                                   // :197
         c->L->recon(g, s.sp, s.prim, rlo, rhi, do_ctu, dt, c->stream);               // :212,230
         if (s.has_tables) apply_face_tables(c, s);                                   // :281 (do_all = false)
@@ -737,6 +761,8 @@ int advance_strang(cmfp_context* c, double dt) {
 // fused kernels cover (caller then takes the staged path), <0 on error.
 int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) {
     if (c->params.time_integrator != CMFP_TI_STRANG) return 0;
+    for (auto& st : c->states)
+        if (st.has_dynamic) return 0;  // 'dynamic' components act on the primitives and on UpdateData::U: stage by stage
     if (!reserve_only)
         for (auto& st : c->states)
             if (st.sp.kind == CMFP_STATE_FIELD && !st.vac_known) {
@@ -773,7 +799,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         const cmfp_action_desc &S = c->actions[src], &K = c->actions[coll];
         if (K.n_states != S.n_states - 1) return 0;
         for (int n = 0; n < K.n_states; ++n)
-            if (K.states[n] != S.states[n]) return 0;
+            if (K.states[n] != S.states[n] || c->states[K.states[n]].desc.n_tracers) return 0;  // sub-components: staged kernels
     }
     // probe coverage (null launches): the tiled 2-D kernel where it applies, else the gather kernels
     const int tile_flag = c->fused == 3 ? 0x100 : 0;  // 3: the LDS-tiled kernel also where the wave-marching one applies
@@ -1431,9 +1457,9 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
             if (A.states[i] < 0 || A.states[i] >= n_states) return fail(c, CMFP_ERR_INVALID, "bad action state index");
         if (A.kind == CMFP_ACTION_CTU) continue;
         if (A.kind == CMFP_ACTION_COLLISIONS_RAMBO) {
-            for (int i = 0; i < A.n_states; ++i)
-                if (c->states[A.states[i]].desc.mixture)
-                    return fail(c, CMFP_ERR_INVALID, "collisions_rambo on a mixture (per-cell mass / charge) is not built");
+            for (int i = 0; i < A.n_states; ++i)  // SpeciesInfo::alpha_idx: a sub-component of the species' own state
+                if (A.species_component[i] < 0 || A.species_component[i] > c->states[A.states[i]].desc.n_tracers)
+                    return fail(c, CMFP_ERR_INVALID, "collisions_rambo: species_component outside 0 .. n_tracers of its state");
             if (A.n_states > 4) return fail(c, CMFP_ERR_INVALID, "at most 4 species per collisions action");
             for (int i = 0; i < A.n_states; ++i)
                 if (c->states[A.states[i]].sp.kind != CMFP_STATE_HYDRO)  // MFP_collisions.cpp:35
@@ -1924,6 +1950,27 @@ int cmfp_state_set_face_values(cmfp_context* c, int s, int dim, int side, int pr
     for (int d = 0; d < 3; ++d)
         for (int sd = 0; sd < 2; ++sd)
             for (int n = 0; n < CMFP_MAX_COMP; ++n) st.has_tables = st.has_tables || st.tab_cell[d][sd][n];
+    return CMFP_OK;
+}
+
+int cmfp_state_set_dynamic(cmfp_context* c, int s, int comp, const double* values) {
+    int r;
+    if ((r = check_ctx(c))) return r;
+    if (s < 0 || s >= (int)c->states.size()) return fail(c, CMFP_ERR_INVALID, "bad state");
+    StateRT& st = c->states[s];
+    if (st.sp.kind != CMFP_STATE_FIELD)  // FieldState::set_udf is the only reader of 'dynamic' (MFP_field.cpp:175-221)
+        return fail(c, CMFP_ERR_INVALID, "'dynamic' components: field states only");
+    if (comp < 0 || comp >= st.sp.nc) return fail(c, CMFP_ERR_INVALID, "bad component index");
+    if (!values) {
+        st.dyn[comp] = nullptr;  // (freed with the context)
+    } else {
+        double*& d = st.dyn[comp];
+        if ((r = dalloc(c, &d, c->g.sc))) return r;
+        HIPCHK(c, hipMemcpyAsync(d, values, sizeof(double) * c->g.sc, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer may be reused on return
+    }
+    st.has_dynamic = false;
+    for (int n = 0; n < CMFP_MAX_COMP; ++n) st.has_dynamic = st.has_dynamic || st.dyn[n];
     return CMFP_OK;
 }
 

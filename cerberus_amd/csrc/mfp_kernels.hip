@@ -446,41 +446,10 @@ __global__ void k_lincomb(Geo g, IBox box, int nc, double* dst, double a, const 
 }
 
 // -------------------------------------------------------------------- sources
-// One cell of Collisions::calc_time_derivative (MFP_collisions.cpp:158-246) with
-// CollisionsRambo::calc_update (MFP_collisions_rambo.cpp:68-126), single-species states
-// (alpha = 1).  out[s][c] is what the reference adds to dU: (U + dt * delta) - U.
+// CollisionsRambo::calc_update (MFP_collisions_rambo.cpp:68-126) over the species of one cell
 template <int NS>
-CMFP_DEV void collisions_rambo_cell(const CollArgs& ca, double dt, const double (*sU)[5], double (*out)[5]) {
-    double rho[NS], m[NS], q[NS], T[NS], q2[NS], nd[NS], vel[NS][3], delta[NS][5];
-#pragma unroll
-    for (int n = 0; n < NS; ++n) {
-        double Tn = 0.0;
-        if (!(sU[n][0] < ca.ez[n])) {  // gas->cons2prim, MFP_collisions.cpp:166-171
-            double Q[5];
-            GasP G{ca.m[n], ca.q[n], ca.gamma[n]};
-            bool ok = hydro_cons2prim(G, sU[n], Q);
-            const double rhoinv = f_rcp(sU[n][0]);
-            Tn = Q[H_P] * rhoinv * ca.m[n];  // MFP_thermally_perfect_gas.cpp:207
-            if (!ok) *ca.err = 1;
-        }
-#pragma unroll
-        for (int c = 0; c < 5; ++c) delta[n][c] = 0.0;
-        if (sU[n][0] > ca.ez[n]) {
-            rho[n] = 1.0 * sU[n][0];
-            m[n] = ca.m[n];
-            q[n] = ca.q[n];
-            T[n] = Tn;
-            q2[n] = q[n] * q[n];
-            nd[n] = f_div(rho[n], m[n]);
-            const double i_rho = f_rcp(rho[n]);
-            vel[n][0] = 1.0 * sU[n][1] * i_rho;
-            vel[n][1] = 1.0 * sU[n][2] * i_rho;
-            vel[n][2] = 1.0 * sU[n][3] * i_rho;
-        } else {
-            rho[n] = m[n] = q[n] = T[n] = q2[n] = nd[n] = 0.0;
-            vel[n][0] = vel[n][1] = vel[n][2] = 0.0;
-        }
-    }
+CMFP_DEV void collisions_rambo_pairs(const CollArgs& ca, const double* rho, const double* m, const double* q, const double* T,
+                                     const double* q2, const double* nd, const double (*vel)[3], double (*delta)[5]) {
     const double lnC = 10.0;
 #pragma unroll
     for (int a = 0; a < NS; ++a) {
@@ -526,6 +495,44 @@ CMFP_DEV void collisions_rambo_cell(const CollArgs& ca, double dt, const double 
             delta[b][4] -= Qx;
         }
     }
+}
+
+// One cell of Collisions::calc_time_derivative (MFP_collisions.cpp:158-246) with
+// CollisionsRambo::calc_update (MFP_collisions_rambo.cpp:68-126), single-species states
+// (alpha = 1).  out[s][c] is what the reference adds to dU: (U + dt * delta) - U.
+template <int NS>
+CMFP_DEV void collisions_rambo_cell(const CollArgs& ca, double dt, const double (*sU)[5], double (*out)[5]) {
+    double rho[NS], m[NS], q[NS], T[NS], q2[NS], nd[NS], vel[NS][3], delta[NS][5];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        double Tn = 0.0;
+        if (!(sU[n][0] < ca.ez[n])) {  // gas->cons2prim, MFP_collisions.cpp:166-171
+            double Q[5];
+            GasP G{ca.m[n], ca.q[n], ca.gamma[n]};
+            bool ok = hydro_cons2prim(G, sU[n], Q);
+            const double rhoinv = f_rcp(sU[n][0]);
+            Tn = Q[H_P] * rhoinv * ca.m[n];  // MFP_thermally_perfect_gas.cpp:207
+            if (!ok) *ca.err = 1;
+        }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) delta[n][c] = 0.0;
+        if (sU[n][0] > ca.ez[n]) {
+            rho[n] = 1.0 * sU[n][0];
+            m[n] = ca.m[n];
+            q[n] = ca.q[n];
+            T[n] = Tn;
+            q2[n] = q[n] * q[n];
+            nd[n] = f_div(rho[n], m[n]);
+            const double i_rho = f_rcp(rho[n]);
+            vel[n][0] = 1.0 * sU[n][1] * i_rho;
+            vel[n][1] = 1.0 * sU[n][2] * i_rho;
+            vel[n][2] = 1.0 * sU[n][3] * i_rho;
+        } else {
+            rho[n] = m[n] = q[n] = T[n] = q2[n] = nd[n] = 0.0;
+            vel[n][0] = vel[n][1] = vel[n][2] = 0.0;
+        }
+    }
+    collisions_rambo_pairs<NS>(ca, rho, m, q, T, q2, nd, vel, delta);
 #pragma unroll
     for (int n = 0; n < NS; ++n)
 #pragma unroll
@@ -551,6 +558,85 @@ __global__ void k_collisions(Geo g, IBox box, SourceArgs a, double dt) {
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int n = 0; n < 5; ++n) a.sp_dU[s][c + n * g.sc] += out[s][n];
+}
+
+// The same where a state has sub-components (tracers: passive scalars or a true mixture): the species of the action is
+// sub-component CollMix::comp of its state (SpeciesInfo::alpha_idx) with the share alpha of the state's density, mass
+// and charge of that sub-component and the state's temperature (MFP_collisions.cpp:160-209); every sub-component's
+// share of U is accounted for, summed again and the original subtracted, the tracers follow from the density shares
+// (:218-257).  Mass fractions as get_alpha_fractions_from_prim gives them (MFP_hydro_gas.cpp:13-27: no clamp).
+template <int NS>
+__global__ void k_collisions_mix(Geo g, IBox box, SourceArgs a, CollMix cm, double dt) {
+    int i, j, k;
+    if (!decode(box, (long)blockIdx.x * TPB + threadIdx.x, i, j, k)) return;
+    const long c = g.at(i, j, k);
+    const CollArgs& ca = a.coll;
+    double sU[NS][7], alpha[NS][3];
+    double rho[NS], m[NS], q[NS], T[NS], q2[NS], nd[NS], vel[NS][3], delta[NS][5];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        const HydroParams& hp = cm.hp[n];
+        const int nt = hp.nt;
+#pragma unroll
+        for (int l = 0; l < 7; ++l) sU[n][l] = l < 5 + nt ? a.sp_U[n][c + l * g.sc] : 0.0;
+        double Tn = 0.0;
+        alpha[n][0] = alpha[n][1] = alpha[n][2] = 0.0;  // (below effective_zero the reference keeps stale fractions)
+        if (!(sU[n][0] < ca.ez[n])) {  // gas->cons2prim + get_alpha_fractions_from_prim, MFP_collisions.cpp:166-171
+            double Q[5];
+            GasP G = hp.gas;
+            if (hp.mix) {  // get_gamma_from_cons / get_mass_from_cons: alpha_i = tracer_i / rho
+                double al[2] = {0.0, 0.0};
+                for (int l = 0; l < nt; ++l) al[l] = f_div(sU[n][5 + l], sU[n][0]);
+                G = mix_gas(hp, al);
+            }
+            bool ok = hydro_cons2prim(G, sU[n], Q);
+            const double rhoinv = f_rcp(sU[n][0]);
+            Tn = Q[H_P] * rhoinv * G.mass;  // MFP_thermally_perfect_gas.cpp:207
+            if (!ok) *ca.err = 1;
+            double sum_alpha = 0.0;
+            for (int l = 0; l < nt; ++l) {
+                alpha[n][l] = sU[n][5 + l] * rhoinv;  // Q[tracer], :212-214
+                sum_alpha += alpha[n][l];
+            }
+            alpha[n][nt] = 1.0 - sum_alpha;
+        }
+#pragma unroll
+        for (int l = 0; l < 5; ++l) delta[n][l] = 0.0;
+        const double al = alpha[n][cm.comp[n]];
+        if (sU[n][0] > ca.ez[n]) {
+            rho[n] = al * sU[n][0];
+            m[n] = cm.m[n];
+            q[n] = cm.q[n];
+            T[n] = Tn;
+            q2[n] = q[n] * q[n];
+            nd[n] = f_div(rho[n], m[n]);
+            const double i_rho = f_rcp(rho[n]);
+            vel[n][0] = al * sU[n][1] * i_rho;
+            vel[n][1] = al * sU[n][2] * i_rho;
+            vel[n][2] = al * sU[n][3] * i_rho;
+        } else {
+            rho[n] = m[n] = q[n] = T[n] = q2[n] = nd[n] = 0.0;
+            vel[n][0] = vel[n][1] = vel[n][2] = 0.0;
+        }
+    }
+    collisions_rambo_pairs<NS>(ca, rho, m, q, T, q2, nd, vel, delta);
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        const int nt = cm.hp[n].nt;
+        double rho_share[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            double sum = 0.0;
+            for (int ai = 0; ai <= nt; ++ai) {
+                double acc = sU[n][l] * alpha[n][ai];
+                if (ai == cm.comp[n]) acc += dt * delta[n][l];
+                if (l == 0) rho_share[ai] = acc;
+                sum += acc;
+            }
+            a.sp_dU[n][c + l * g.sc] += sum - sU[n][l];
+        }
+        for (int ti = 0; ti < nt; ++ti) a.sp_dU[n][c + (5 + ti) * g.sc] += rho_share[ti] - sU[n][5 + ti];
+    }
 }
 
 // One cell of Plasma5::implicit_solve (MFP_plasma5.cpp:324-448).  The
@@ -1337,6 +1423,16 @@ static void l_source(const Geo& g, const SourceArgs& a, double dt, hipStream_t s
     case 4: l_source_n<4>(g, a, dt, st); break;
     }
 }
+static void l_collisions_mix(const Geo& g, const SourceArgs& a, const CollMix& cm, double dt, hipStream_t st) {
+    const IBox b = valid_box(g);
+    switch (a.n_species) {
+    case 1: LAUNCH((k_collisions_mix<1>), b.npts(), st, g, b, a, cm, dt); break;
+    case 2: LAUNCH((k_collisions_mix<2>), b.npts(), st, g, b, a, cm, dt); break;
+    case 3: LAUNCH((k_collisions_mix<3>), b.npts(), st, g, b, a, cm, dt); break;
+    case 4: LAUNCH((k_collisions_mix<4>), b.npts(), st, g, b, a, cm, dt); break;
+    default: break;
+    }
+}
 static void l_collisions(const Geo& g, const SourceArgs& a, double dt, hipStream_t st) {
     IBox b = valid_box(g);
     switch (a.n_species) {
@@ -1580,7 +1676,7 @@ const Launchers* launchers() {
                                 l_divergence, l_copy,         l_zero,           l_add,             l_lincomb,
                                 l_source,    l_max_speed,     l_plasma_dt,      l_viscous,   l_visc_stability, l_table_store, l_fill_dim,        l_pack, l_fill_multi,
                                 ctu_fused,   l_source_fused,  l_collisions, l_ctu_gather, ctu_field3d, ctu_field_src, ctu_interior, ctu_march2, ctu_march_field, field_vacuum_check, l_source_coef, l_source_fused_box, l_leaf_reconstruct, l_leaf_riemann,  l_leaf_cons2prim,
-                                l_leaf_prim2cons, l_reduce_final, l_reduce_many, l_first_invalid, l_new_dt, ctu_march_tab, l_fold_new_dt};
+                                l_leaf_prim2cons, l_reduce_final, l_reduce_many, l_first_invalid, l_new_dt, ctu_march_tab, l_fold_new_dt, l_collisions_mix};
     return &L;
 }
 

@@ -102,6 +102,14 @@ struct CollArgs {
     int* err;                             // device flag: primitive values outside of physical bounds
 };
 
+// collisions_rambo over states with sub-components (tracers): per species of the action the sub-component that takes
+// part (cmfp_action_desc::species_component), its mass and charge, and the state's gas (for cons2prim of a mixture)
+struct CollMix {
+    int comp[4];
+    double m[4], q[4];
+    HydroParams hp[4];
+};
+
 // a species that is a mixture (cmfp_state_desc::mixture): mass and charge of a cell follow its mass fractions
 // (HydroGas::get_mass_from_cons / get_charge_from_cons, MFP_hydro_gas.cpp:72-96,123-150).  nt = 0: the constants.
 struct SpeciesMix {
@@ -282,6 +290,8 @@ struct Launchers {
                          int* err, unsigned long long* red, int part, const MarchTab& tab, hipStream_t);
     // reduce_many (at most RedJobs::MAX jobs, one workgroup) followed by new_dt, in one launch
     void (*fold_new_dt)(const RedJobs&, const DtPlan&, const unsigned long long* red, double* dt, double* log, int idx, hipStream_t);
+    // `collisions` where a state has sub-components (tracers / a mixture): the shares of every sub-component accounted for
+    void (*collisions_mix)(const Geo&, const SourceArgs&, const CollMix&, double dt, hipStream_t);
 };
 
 }  // namespace cmfp

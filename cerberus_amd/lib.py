@@ -28,6 +28,7 @@ SYMBOLS = [
     ("cmfp_state_device_view", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                          C.POINTER(C.c_longlong * 3), C.POINTER(C.c_int)]),
     ("cmfp_state_set_face_values", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp]),
+    ("cmfp_state_set_dynamic", C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
     ("cmfp_update_begin", C.c_int, [C.c_void_p]),
     ("cmfp_action_get_data", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     ("cmfp_action_calc_time_derivative", C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double]),

@@ -1298,7 +1298,7 @@ def problem_from_lua(interp, geometry, action_map=None):
         if action_map and t in action_map:
             ignored.append(f"actions.{name}: type '{t}' -> '{action_map[t]}'")
             d["type"] = t = action_map[t]
-            d = {k: v for k, v in d.items() if k in ("type", "states", "corner_transport", "solver", "cross_sections")}
+            d = {k: v for k, v in d.items() if k in ("type", "states", "corner_transport", "solver", "cross_sections", "species")}
             d.setdefault("corner_transport", True)
         if t == "elliptic" and int(d.get("projection", 0)) == 1 and d.get("state") in states:
             # divergence projection (cmfp_elliptic_project_bc): periodic directions and outflow / symmetry / inflow

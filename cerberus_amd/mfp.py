@@ -87,6 +87,14 @@ class MFP:
             raise NotImplementedError("time-dependent boundary functions: 'strang' only (one flux evaluation at t + dt)")
         for s in range(self.n_states):
             self._upload_face_values(s, 0.0)
+        # 'dynamic' components (field states): tabulated at the time the fluxes are evaluated at, before every step
+        # when they depend on time, else once; such a state runs stage by stage, step by step
+        self._dynamic = [s for s in range(self.n_states) if p.dynamic_entries(s)]
+        self._dynamic_t = [s for s in self._dynamic if p.dynamic_depends_on_time(s)]
+        if self._dynamic:
+            self._device_dt = False
+        for s in self._dynamic:
+            self._upload_dynamic(s, 0.0)
         self._cb = None
         self._bufs = {}
         self._exchange_device = exchange_device
@@ -174,10 +182,17 @@ class MFP:
             self._chk(self.L.cmfp_state_set_face_values(self.h, s, d, side, prim, cell.ctypes.data_as(lib.dp),
                                                          face.ctypes.data_as(lib.dp)))
 
+    def _upload_dynamic(self, s, t):
+        ng = self.device_view(s)[1]
+        for comp, values in self.p.dynamic_tables(s, ng, t, self.block_lo, self.block_n):
+            self._chk(self.L.cmfp_state_set_dynamic(self.h, s, comp, values.ctypes.data_as(lib.dp)))
+
     # -- stepping ---------------------------------------------------------
     def advance(self, dt):
         for s in self._time_bc:     # the flux stage of the Strang step is evaluated at time + dt (MFP_advance.cpp:208-217)
             self._upload_face_values(s, self.time + dt)
+        for s in self._dynamic_t:   # calc_spatial_derivative(time + dt) in the Strang step, (time) in euler / RK2 (:72-104)
+            self._upload_dynamic(s, self.time + dt if self.p.scheme == "strang" else self.time)
         self._chk(self.L.cmfp_advance(self.h, self.time, dt))
         for fs, species in self._elliptic:     # act->apply_change (MFP_advance.cpp:49)
             if self.world > 1 and self.p.dim > 1:

@@ -231,6 +231,24 @@ def collisions_relaxation(n=4, neutral=False):
     }
 
 
+def collisions_sub_component(n=4, neutral=False, passive=False):
+    """collisions_relaxation with the beam state A made of two sub-components (gas.names = {A_C, A_He}) of which the
+    action's `species` list names the second one: a carbon / helium mixture (different mass and charge), or with
+    passive=True two labels of the same gas.  The mass fraction varies over the block."""
+    cfg = collisions_relaxation(n, neutral)
+    A = cfg["states"]["A"]
+    if passive:
+        A["gas"].update(mass=[12.0, 12.0], charge=[6.0, 6.0], gamma=[5 / 3, 5 / 3])
+    else:
+        A["gas"].update(mass=[12.0, 4.0], charge=[6.0, 2.0], gamma=[5 / 3, 1.4])
+    A["gas"]["names"] = ["A_C", "A_He"]
+    A["value"]["alpha"] = [lambda d: 0.4 + 0.3 * np.sin(np.pi * d["x"]) * np.cos(np.pi * d["y"])]
+    act = cfg["actions"]["collisions"]
+    act["species"] = ["A_He", "B"]
+    act["cross_sections"] = {"A_He": {"B": 1.0e-20 if neutral else 1.0}}
+    return cfg
+
+
 def viscous_vortex_2d(n=384, recon="O6"):
     """Exec/testing/Viscous-Vortex (problem_definition.lua, vortex.inputs): a decaying Lamb-Oseen vortex
     (Munoz et al. 2013) in a viscous gas, PowerLaw viscosity with mu0 = 0.08, O6 + HLLC + CTU, `euler`

@@ -157,8 +157,7 @@ typedef struct {
      * The plasma5 / Lorentz sources and the plasma dt limit read mass and charge of a cell the same way
      * (get_mass_from_cons / get_charge_from_cons, MFP_plasma5.cpp:199-202,364-365,544-545; species_charge).
      * Built on the stage-by-stage kernels (CTU / RK2 / euler updates, viscous fluxes, Dirichlet faces, sources,
-     * dt limits) and in the charge density of cmfp_elliptic_project; a mixture state in a collisions_rambo action
-     * is refused by cmfp_create. */
+     * dt limits, collisions_rambo) and in the charge density of cmfp_elliptic_project. */
     int mixture;
     double species_mass[CMFP_MAX_TRACERS + 1];
     double species_gamma[CMFP_MAX_TRACERS + 1];
@@ -173,12 +172,17 @@ typedef struct {
     int n_states;
     /* CTU: the states it transports.  plasma5/Lorentz: species in the order
      * of the Lua 'states' list, then the field last.  collisions_rambo: the
-     * hydro states (= species, single-species gases) in list order. */
+     * hydro states in list order (one species of each, see species_component). */
     int states[CMFP_MAX_ACTION_STATES];
     /* collisions_rambo: hard-sphere cross sections between species a and b of the
      * list, already divided by x_ref^2 and symmetric (MFP_collisions_rambo.cpp:39-55);
      * only pairs with a neutral partner use them. */
     double cross_sections[CMFP_MAX_ACTION_STATES][CMFP_MAX_ACTION_STATES];
+    /* collisions_rambo: the sub-component of state n that takes part (the entry of the Lua 'species' list found in
+     * gas.names, Collisions::SpeciesInfo::alpha_idx MFP_collisions.cpp:43-57); 0 .. n_tracers of that state, 0 for
+     * a single-species gas.  One species per state, in list order: the reference reads the species' data with the
+     * species index (:181-190), so any other arrangement is refused by cmfp_create. */
+    int species_component[CMFP_MAX_ACTION_STATES];
 } cmfp_action_desc;
 
 typedef struct cmfp_context cmfp_context;
@@ -238,6 +242,17 @@ int cmfp_state_device_view(cmfp_context* ctx, int state, double** dptr, int* ngr
  * physical face of the rank's own block), so that all ranks take the same kernel path. */
 int cmfp_state_set_face_values(cmfp_context* ctx, int state, int dim, int side, int prim,
                                const double* cell_values, const double* face_values);
+
+/* 'dynamic' components of a field state (states.<name>.dynamic = {'x_B', ...}; FieldState::set_udf
+ * MFP_field.cpp:175-221 -> EulerianState::dynamic_functions): inside calc_primitives the listed components take the
+ * value of their initialisation function at (x, y, z, t) — in the primitives the fluxes are built from and, through
+ * prim2cons, in the conserved copy the actions of the step work on (UpdateData::U; MFP_eulerian.cpp:403-423), not in
+ * the state's own data.  `values`: the function tabulated by the caller over the block grown by the context's ghost
+ * width (cmfp_state_device_view), i fastest, host pointer, at the time the integrator evaluates its fluxes at
+ * (strang: time + dt, MFP_advance.cpp:208-217; euler / RK2: time, :72-104); NULL removes the entry.  The reference
+ * reads 'dynamic' for field states only: hydro states are refused.  A state with an entry runs on the
+ * stage-by-stage kernels, step by step (cmfp_advance_steps returns 1). */
+int cmfp_state_set_dynamic(cmfp_context* ctx, int state, int comp, const double* values);
 
 /* ---- Action plugin API, one call per virtual of class Action
  * (actions/MFP_action.H:60-90).  They act on the context's UpdateData

@@ -743,6 +743,10 @@ struct StateDef {
     };
     FaceTab tab[3][2][CMFP_MAX_COMP];
     int tng = 0;
+    // 'dynamic' components (EulerianState::dynamic_functions, MFP_eulerian.H:54; read for field states only,
+    // MFP_field.cpp:175-221): the function values over grow(domain, dyn_ng), i fastest; empty: none
+    std::vector<Real> dyn[CMFP_MAX_COMP];
+    int dyn_ng = 0;
     bool inflow(int d, int side) const {  // where_is_inflow == ext_dir  (:72-87)
         for (int n = 0; n < CMFP_MAX_COMP; ++n)
             if (!tab[d][side][n].cell.empty()) return true;
@@ -919,7 +923,7 @@ static void st_speed_from_cons(const StateDef& S, const Real* U, Real* s) {
     s[0] = s[1] = s[2] = S.fastest_speed;  // MFP_field.H:72-75
 }
 
-// EulerianState::calc_primitives  MFP_eulerian.cpp:313-433 (no EB, no dynamic functions)
+// EulerianState::calc_primitives  MFP_eulerian.cpp:313-433 (no EB; the dynamic functions: apply_dynamic below)
 static void calc_primitives(const StateDef& S, const Box& box, const Fab& cons, Fab& prim) {
     Real U[CMFP_MAX_COMP], Q[CMFP_MAX_COMP];
     prim.resize(box, S.n_prim);
@@ -930,6 +934,24 @@ static void calc_primitives(const StateDef& S, const Box& box, const Fab& cons, 
                 st_cons2prim(S, U, Q);
                 for (int n = 0; n < S.n_prim; ++n) prim(i, j, k, n) = Q[n];
             }
+}
+
+// The 'dynamic' part of calc_primitives (MFP_eulerian.cpp:403-423): the listed primitives take the value of their
+// initialisation function at (x, y, z, t), and prim2cons writes the result back into the conserved copy the action
+// works on (UpdateData::U, shared with the actions that follow in the same step).  Field states: prim = cons.
+static void apply_dynamic(const StateDef& S, int DIM, const Box& domain, const Box& box, Fab& cons, Fab& prim) {
+    if (S.hydro()) return;  // (HydroState::set_udf does not read 'dynamic')
+    const Box tb = grow(domain, S.dyn_ng, DIM);
+    for (int n = 0; n < S.n_cons; ++n) {
+        if (S.dyn[n].empty()) continue;
+        for (int k = box.lo[2]; k <= box.hi[2]; ++k)
+            for (int j = box.lo[1]; j <= box.hi[1]; ++j)
+                for (int i = box.lo[0]; i <= box.hi[0]; ++i) {
+                    const Real v = S.dyn[n][(size_t)tab_at(tb, i, j, k)];
+                    prim(i, j, k, n) = v;
+                    cons(i, j, k, n) = v;
+                }
+    }
 }
 
 // EulerianState::update_boundary_cells  MFP_eulerian.cpp:435-511 with State::get_bc_limits
@@ -1571,6 +1593,7 @@ struct Sim {
                 Fab R_lo[3], R_hi[3], fluxes[3];
                 const Box pbox = grow(box, S.num_grow, DIM);
                 calc_primitives(S, pbox, cons, prim);
+                apply_dynamic(S, DIM, G.domain, pbox, cons, prim);                // MFP_eulerian.cpp:403-423
                 update_boundary_cells(S, DIM, G.domain, G.periodic, pbox, prim);  // MFP_CTU_hydro.cpp:197
                 if (S.hydro())
                     calc_reconstruction_hydro(S, DIM, rbox, prim, R_lo, R_hi);
@@ -1775,7 +1798,11 @@ struct Sim {
     }
 
     // Collisions::calc_time_derivative MFP_collisions.cpp:95-267 with CollisionsRambo::calc_update
-    // MFP_collisions_rambo.cpp:68-126; single-species states (alpha = 1, no tracers, no EB).
+    // MFP_collisions_rambo.cpp:68-126 (no EB).  A state of several sub-components (tracers: passive or a mixture)
+    // takes part with the one named in the action's `species` list (SpeciesInfo::alpha_idx, :47-57 =
+    // cmfp_action_desc::species_component).  The reference reads U[n], Q[n], alpha[n] and states[n] with the
+    // species index (:181-190), which is the species' own state only where species n lives in state n: that is the
+    // configuration restated here (one species per state, in list order).
     void collisions_rambo(int a, std::vector<UpdateData>& update, Real dt) {
         const cmfp_action_desc& A = actions[a].desc;
         const int n_species = A.n_states;
@@ -1793,30 +1820,41 @@ struct Sim {
         for (long b = 0; b < (long)boxes.size(); ++b) {
             const Box& box = boxes[b];
             Info sp[CMFP_MAX_ACTION_STATES];
-            Real U[CMFP_MAX_ACTION_STATES][5], Q[CMFP_MAX_ACTION_STATES][8];
+            Real U[CMFP_MAX_ACTION_STATES][HC_NUM + CMFP_MAX_TRACERS], Q[CMFP_MAX_ACTION_STATES][HP_NUM + CMFP_MAX_TRACERS];
+            Real alpha[CMFP_MAX_ACTION_STATES][CMFP_MAX_TRACERS + 1];
+            Real accounting[CMFP_MAX_TRACERS + 1][5];
+            for (int si = 0; si < n_species; ++si)
+                for (int l = 0; l <= CMFP_MAX_TRACERS; ++l) alpha[si][l] = 0.0;
             for (int k = box.lo[2]; k <= box.hi[2]; ++k)
                 for (int j = box.lo[1]; j <= box.hi[1]; ++j)
                     for (int i = box.lo[0]; i <= box.hi[0]; ++i) {
                         for (int si = 0; si < n_species; ++si) {
                             const StateDef& S = states[A.states[si]];
-                            for (int l = 0; l < 5; ++l) U[si][l] = update[A.states[si]].U[b](i, j, k, l);
+                            for (int l = 0; l < S.n_cons; ++l) U[si][l] = update[A.states[si]].U[b](i, j, k, l);
                             if (U[si][Density] < S.desc.effective_zero) {
-                                for (int l = 0; l < 8; ++l) Q[si][l] = 0.0;
+                                for (int l = 0; l < HP_NUM + S.gas.nt; ++l) Q[si][l] = 0.0;
+                                // (the reference leaves alpha at the previous cell's values here, :166-171)
                             } else {
-                                Gas g5 = S.gas;  // the collision terms use the five hydro components only
-                                g5.nt = 0;
-                                gas_cons2prim(g5, U[si], Q[si]);
+                                gas_cons2prim(S.gas, U[si], Q[si]);
+                                // get_alpha_fractions_from_prim MFP_hydro_gas.cpp:13-27 (no clamp)
+                                Real sum_alpha = 0.0;
+                                for (int l = 0; l < S.gas.nt; ++l) {
+                                    alpha[si][l] = Q[si][HP_NUM + l];
+                                    sum_alpha += alpha[si][l];
+                                }
+                                alpha[si][S.gas.nt] = 1.0 - sum_alpha;
                             }
                         }
                         for (int n = 0; n < n_species; ++n) {
                             const StateDef& S = states[A.states[n]];
+                            const int ai = A.species_component[n];
                             Info& info = sp[n];
                             for (int l = 0; l < 5; ++l) info.delta[l] = 0.0;
-                            const Real al = 1.0;  // get_alpha_fractions_from_prim, single species
+                            const Real al = alpha[n][ai];
                             if (U[n][Density] > S.desc.effective_zero) {
                                 info.rho = al * U[n][Density];
-                                info.m = S.gas.mass;
-                                info.q = S.gas.charge;
+                                info.m = S.gas.sm[ai];
+                                info.q = S.gas.sq[ai];
                                 info.T = Q[n][Temp];
                                 info.q2 = info.q * info.q;
                                 info.n = info.rho / info.m;
@@ -1866,17 +1904,22 @@ struct Sim {
                                 sdb.delta[Eden] -= Qx;
                             }
                         }
-                        // accounting (:218-246): original amount * alpha + dt * delta, minus the original
+                        // accounting (:218-257): every sub-component's share alpha_ai U, the participating one plus
+                        // dt delta, summed again, minus the original; tracers from the density share of their component
                         for (int si = 0; si < n_species; ++si) {
+                            const StateDef& S = states[A.states[si]];
                             Fab& U4 = update[A.states[si]].U[b];
                             Fab& dU4 = update[A.states[si]].dU[b];
+                            for (int ai = 0; ai <= S.gas.nt; ++ai)
+                                for (int ci = 0; ci < 5; ++ci) accounting[ai][ci] = U[si][ci] * alpha[si][ai];
+                            for (int ci = 0; ci < 5; ++ci) accounting[A.species_component[si]][ci] += dt * sp[si].delta[ci];
                             for (int ci = 0; ci < 5; ++ci) {
-                                Real acc = U[si][ci] * 1.0;
-                                acc += dt * sp[si].delta[ci];
                                 Real sum = 0.0;
-                                sum += acc;
+                                for (int ai = 0; ai <= S.gas.nt; ++ai) sum += accounting[ai][ci];
                                 dU4(i, j, k, ci) += sum - U4(i, j, k, ci);
                             }
+                            for (int ti = 0; ti < S.gas.nt; ++ti)
+                                dU4(i, j, k, HC_NUM + ti) += accounting[ti][Density] - U4(i, j, k, HC_NUM + ti);
                         }
                     }
         }
@@ -2315,6 +2358,16 @@ void orc_set_face_values(void* h, int s, int d, int side, int prim, int tng, con
     const Box cb = tab_box(S->G.domain, S->G.DIM, tng, d, side, false), fb = tab_box(S->G.domain, S->G.DIM, tng, d, side, true);
     st.tab[d][side][prim].cell.assign(cell, cell + cb.npts());
     st.tab[d][side][prim].face.assign(face, face + fb.npts());
+}
+// 'dynamic' component `comp` of state s: values over grow(domain, ng), i fastest (n = 0 removes the entry)
+void orc_set_dynamic(void* h, int s, int comp, int ng, const double* values, long n) {
+    Sim* S = (Sim*)h;
+    StateDef& st = S->states[s];
+    st.dyn_ng = ng;
+    if (values && n > 0)
+        st.dyn[comp].assign(values, values + n);
+    else
+        st.dyn[comp].clear();
 }
 int orc_num_boxes(void* h) { return (int)((Sim*)h)->boxes.size(); }
 

@@ -398,6 +398,14 @@ class OracleSim:
         self._time_bc = [s for s in range(len(problem.state_names)) if problem.face_values_depend_on_time(s)]
         for s in range(len(problem.state_names)):
             self._set_face_values(s, 0.0)
+        self._dynamic = [s for s in range(len(problem.state_names)) if problem.dynamic_entries(s)]
+        self._dynamic_t = [s for s in self._dynamic if problem.dynamic_depends_on_time(s)]
+        for s in self._dynamic:
+            self._set_dynamic(s, 0.0)
+
+    def _set_dynamic(self, s, t):
+        for comp, values in self.p.dynamic_tables(s, self.TNG, t):
+            lib().orc_set_dynamic(self.h, C.c_int(s), C.c_int(comp), C.c_int(self.TNG), _p(values), C.c_long(values.size))
 
     TNG = 4    # ghost width of the Dirichlet tables handed to the oracle (>= every num_grow)
 
@@ -427,6 +435,8 @@ class OracleSim:
     def advance(self, dt):
         for s in self._time_bc:
             self._set_face_values(s, self.time + dt)
+        for s in self._dynamic_t:
+            self._set_dynamic(s, self.time + dt if self.p.scheme == "strang" else self.time)
         self.time += dt
         lib().orc_clear_error()
         lib().orc_advance(self.h, C.c_double(dt))

@@ -271,6 +271,27 @@ def test_collisions_relaxation_parity(oracle, neutral):
         m.close()
 
 
+@pytest.mark.parametrize("passive", [False, True], ids=["mixture", "passive_labels"])
+@pytest.mark.parametrize("neutral", [False, True])
+def test_collisions_sub_component_parity(oracle, neutral, passive):
+    """The species of the action is the second sub-component of a two-component state (gas.names + `species`,
+    MFP_collisions.cpp:43-60): its share alpha of the density, its own mass and charge, the state's temperature;
+    every sub-component's share accounted for and the tracer updated from the density share (:160-257).
+    Parity unpinned (the reference holds no fixture for collisions): the oracle is the restatement."""
+    for mode, tol in ((abi.FP_STRICT, 0.0 if neutral else 1e-13), (abi.FP_FAST, 1e-12)):
+        P = config.Problem(problems.collisions_sub_component(8, neutral, passive), fp_mode=mode)
+        ref = oracle.OracleSim(P)
+        m = _gpu(P)
+        for _ in range(40):
+            ref.advance(1e-4)
+            m.advance(1e-4)
+        for s in range(2):
+            assert rel_linf(m.download(s), ref.get_state(s)) <= tol, (neutral, passive, mode, s)
+        if mode == abi.FP_STRICT and neutral:
+            assert np.array_equal(m.download(0), ref.get_state(0))
+        m.close()
+
+
 @pytest.mark.parametrize("n", [(64, 64), (61, 37), (120, 9)])
 def test_field_materials_select_the_kernel(oracle, n):
     """The marching vacuum kernel takes the 2-D O6 field only where mu = ep = 1 on the whole block (checked on the

@@ -362,9 +362,19 @@ def test_mixture_with_elliptic_action_gpu(oracle, mode):
 
 @pytest.mark.gpu
 def test_mixture_refusals_of_the_library():
-    """a mixture in a collisions action or with Dirichlet face data: CMFP_ERR_INVALID, nothing silently approximated"""
+    """a collisions species that names no sub-component of its state: CMFP_ERR_INVALID, nothing silently approximated
+    (a mixture in a collisions action itself is built: tests/test_gpu_actions.py::test_collisions_sub_component_parity)"""
     cfg = problems.orszag_tang_two_fluid_2d(16, collisions=True)
     problems.with_mixture(cfg, "ion", [0.5], [1.0, 2.0], [5 / 3, 1.4])
+    with pytest.raises(ValueError):     # the default species are the state names: "ion" is no sub-component of ion_0, ion_1
+        config.Problem(cfg).action_descs()         # ("Couldn't find sub-component", MFP_collisions.cpp:59)
+    cfg["actions"]["collisions"]["species"] = ["ion_1", "electron"]
+    P = config.Problem(cfg)
+    descs = P.action_descs()
+    for a in descs:
+        if a.kind == abi.ACTION["collisions_rambo"]:
+            a.species_component[0] = 2          # the ions have sub-components 0 and 1
+    P.action_descs = lambda: descs
     with pytest.raises(lib.CmfpError) as e:
-        _gpu(config.Problem(cfg))
+        _gpu(P)
     assert e.value.code == abi.ERR_INVALID

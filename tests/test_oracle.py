@@ -201,6 +201,45 @@ def test_implicit_and_explicit_sources_agree_for_small_dt(oracle):
 
 # ---- collisions_rambo (no reference fixture: parity unpinned; physics properties) --------
 @pytest.mark.parametrize("neutral", [False, True])
+def test_collisions_on_a_sub_component(oracle, neutral):
+    """A species of the action that is one sub-component of a mixture state (gas.names + the action's `species`
+    list, MFP_collisions.cpp:43-60,160-257): what the beam loses the background gains, the sub-components' densities
+    do not move (S = 0), and two labels of one gas (passive tracer) give the five hydro components of the same
+    problem without labels when the labelled share is the whole state."""
+    P = config.Problem(problems.collisions_sub_component(4, neutral))
+    assert list(P.action_descs()[0].species_component)[:2] == [1, 0]
+    sim = oracle.OracleSim(P)
+    U0 = [sim.get_state(s).copy() for s in range(2)]
+    for _ in range(40):
+        sim.advance(1e-4)
+    U1 = [sim.get_state(s) for s in range(2)]
+    for c in (1, 2, 3, 4):
+        t0, t1 = sum(u[c].sum() for u in U0), sum(u[c].sum() for u in U1)
+        assert abs(t1 - t0) <= 1e-14 * max(abs(t0), 1.0), c
+    assert np.array_equal(U1[0][0], U0[0][0]) and np.allclose(U1[0][5], U0[0][5], rtol=1e-15, atol=0)
+    assert U1[0][1].mean() < 0.95 * U0[0][1].mean()          # the beam slows down on the background
+    # the whole state labelled as the participating sub-component = the problem without labels, to rounding
+    cfg = problems.collisions_sub_component(4, neutral, passive=True)
+    cfg["states"]["A"]["value"]["alpha"] = [0.0]              # all of A is its second sub-component (A_He)
+    a = oracle.OracleSim(config.Problem(cfg))
+    b = oracle.OracleSim(config.Problem(problems.collisions_relaxation(4, neutral)))
+    for _ in range(10):
+        a.advance(1e-4)
+        b.advance(1e-4)
+    for s in range(2):
+        assert np.allclose(a.get_state(s)[:5], b.get_state(s), rtol=1e-13, atol=0)
+    # a species that is not a sub-component of the state at its own position: the reference reads the wrong
+    # state's data there (MFP_collisions.cpp:181-190); refused by the configuration layer
+    cfg = problems.collisions_sub_component(4, neutral)
+    cfg["actions"]["collisions"]["species"] = ["B", "A_He"]
+    with pytest.raises(NotImplementedError):
+        config.Problem(cfg).action_descs()
+    cfg["actions"]["collisions"]["species"] = ["A_He", "nobody"]
+    with pytest.raises(ValueError):
+        config.Problem(cfg).action_descs()
+
+
+@pytest.mark.parametrize("neutral", [False, True])
 def test_collisions_conserve_and_equilibrate(oracle, neutral):
     """Exec/testing/Collisions: the beam and the background exchange momentum and energy only
     with each other (R and Q enter with opposite signs, MFP_collisions_rambo.cpp:112-123) and
