@@ -811,7 +811,11 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
             for (int i = 0; i < A.n_states; ++i) {
                 const StatePhys& sp = c->states[A.states[i]].sp;
                 if (sp.kind == CMFP_STATE_HYDRO && sp.visc.kind) return 0;  // viscous fluxes: stage-by-stage kernels only
-                if (sp.kind == CMFP_STATE_HYDRO && sp.hp.nt) return 0;      // passive scalars: stage-by-stage kernels only
+                // passive scalars: the 2-D marching kernel (probed below); true mixtures: stage-by-stage kernels only
+                // (desc.mixture also where only the charges differ: the sources read a per-cell charge, staged kernels)
+                if (sp.kind == CMFP_STATE_HYDRO && sp.hp.nt &&
+                    (sp.hp.mix || c->states[A.states[i]].desc.mixture || c->g.dim != 2 || c->fused != 1))
+                    return 0;
                 if (c->states[A.states[i]].has_tables) {  // Dirichlet face data: the 2-D hydro marching kernel, else stage by stage
                     MarchTab none_tab;
                     std::memset(&none_tab, 0, sizeof(none_tab));

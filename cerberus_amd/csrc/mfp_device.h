@@ -711,6 +711,7 @@ template <int RECON_, int FLUX_> struct HydroPhys {
     static constexpr int NQ = 5;  // primitive comps carried
     static constexpr int NF = 5;  // flux comps that can be non-zero
     static constexpr int RECON = RECON_;
+    static constexpr int FLUX = FLUX_;
     static constexpr bool IS_HYDRO = true;
     typedef HydroParams Params;
 
@@ -732,6 +733,31 @@ template <int RECON_, int FLUX_> struct HydroPhys {
         rot_g2l(L, H_U, d);
         rot_g2l(R, H_U, d);
         hydro_riemann<FLUX_>(L, R, P.gas.gamma, P.shock_threshold, F);
+        rot_l2g(F, 1, d);
+    }
+    // the same with NT passive scalars: aL, aR the mass fractions of the two face states, Ft their fluxes (the hybrid
+    // solver leaves them undefined in the reference, quirk Q5: refused with tracers by cmfp_create)
+    template <int NT>
+    static CMFP_DEV void riemann_tracers(const Params& P, int d, const double* Lg, const double* Rg, const double* aL, const double* aR,
+                                         double* F, double* Ft) {
+        double L[5], R[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            L[n] = Lg[n];
+            R[n] = Rg[n];
+        }
+        rot_g2l(L, H_U, d);
+        rot_g2l(R, H_U, d);
+        HllAux x;
+        if (FLUX_ == 1) {
+            hlle_solve(L, R, P.gas.gamma, P.gas.gamma, F, &x);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) Ft[t] = hlle_tracer_flux(x, L, R, aL[t], aR[t]);
+        } else {
+            hllc_solve(L, R, P.gas.gamma, P.gas.gamma, F, &x);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) Ft[t] = hllc_tracer_flux(x, L, R, aL[t], aR[t]);
+        }
         rot_l2g(F, 1, d);
     }
 };
@@ -863,6 +889,25 @@ template <int RECON_, int FLUX_> struct HydroF : HydroPhys<RECON_, FLUX_> {
 #pragma unroll
         for (int n = 0; n < 5; ++n) U[n] += k * dF[n];
         return hydro_cons2prim(P.gas, U, Q);
+    }
+    // with NT passive scalars A = alpha of the face state: tracer = alpha rho, += k dT, alpha = tracer / rho' with the
+    // corrected density (k_correct in mfp_kernels.hip; MFP_thermally_perfect_gas.cpp:212-214,243-245)
+    template <int NT>
+    static CMFP_DEV bool correct_tracers(const Params& P, double* Q, double* A, double k, const double* dF, const double* dT) {
+        double U[5], T[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            T[t] = A[t] * Q[H_RHO];
+            T[t] += k * dT[t];
+        }
+        hydro_prim2cons(P.gas, Q, U);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) U[n] += k * dF[n];
+        const bool ok = hydro_cons2prim(P.gas, U, Q);
+        const double rinv = f_rcp(U[0]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) A[t] = T[t] * rinv;
+        return ok;
     }
 };
 template <int RECON_> struct FieldF : FieldPhys<RECON_> {

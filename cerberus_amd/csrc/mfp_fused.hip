@@ -520,6 +520,7 @@ int ctu_fused(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout
     if (!tile_only && ctu_march(g, sp, Uin, Uout, do_ctu, dt, touches, err, red, part | wrap, st)) return 1;
     if (!tile_only && ctu_march_field(g, sp, Uin, Uout, do_ctu, dt, touches, nullptr, part | wrap, nullptr, st)) return 1;
     if (wrap) return 0;
+    if (sp.kind == 0 && sp.hp.nt) return 0;  // passive scalars: the marching kernel only
 #define HY(R, F)                                                                                                    \
     if (sp.recon == R && sp.flux == F)                                                                              \
         return launch2d<HydroF<R, F>, CMFP_HBX, CMFP_HBY>(g, sp.hp, sp, Uin, Uout, do_ctu, dt, touches, err, red, part, st);

@@ -1618,6 +1618,7 @@ int ctu_march_tab(const Geo&, const StatePhys&, const double* Uin, double* Uout,
                   int* err, unsigned long long* red, int part, const MarchTab& tab, hipStream_t);
 static int l_ctu_gather(const Geo& g, const StatePhys& sp, const double* Uin, double* Uout, const Ptr3& F1, const Ptr3& F2,
                         int do_ctu, double dt, const int touches[3][2], int* err, unsigned long long* red, hipStream_t st) {
+    if (sp.kind == 0 && sp.hp.nt) return 0;  // passive scalars: the 2-D marching kernel or stage by stage
     if (g.dim == 1) return ctu_gather_1(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);
     if (g.dim == 2) return ctu_gather_2(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);
     return ctu_gather_3(g, sp, Uin, Uout, F1, F2, do_ctu, dt, touches, err, red, st);

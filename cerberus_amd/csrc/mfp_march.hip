@@ -48,10 +48,18 @@ struct MarchStates {
 // in place of their own (EulerianState::update_boundary_cells MFP_eulerian.cpp:435-511), the outside face states the
 // values at the face centres, once before sweep 1 — kept, like the reference keeps them in its face arrays — and
 // again after the fill rules before sweep 2 (face_bc :838-877).  Single-state launches of blocks with physical faces.
-template <class Phys, bool HAS_BC, bool REDUCE, bool PRO, bool TAB = false>
-__global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S, double dt, MarchBC bc, int* err, MarchSel sel,
-                                                      SourcePro pro, MarchTab tab) {
+// NT: passive scalars (HydroState::n_tracers, species of equal mass / charge / gamma): the mass fractions alpha_t =
+// tracer_t / rho ride through the same pipeline — limited slopes and half-step trace like every primitive
+// (MFP_hydro.cpp:982-995), the tracer fluxes of HLLC / HLLE from the side and wave speeds of the hydro solve
+// (MFP_hllc.cpp:100-183, MFP_hydro_hlle.cpp:75-118), transverse corrections as tracer = alpha rho, += k dF,
+// alpha = tracer / rho' (prim2cons / cons2prim, MFP_thermally_perfect_gas.cpp:212-214,243-245).  These instances
+// hold about 60 more values per lane and run at one wave per SIMD.
+template <class Phys, bool HAS_BC, bool REDUCE, bool PRO, bool TAB = false, int NT = 0>
+__global__ __launch_bounds__(64, NT ? 1 : 2) void k_ctu_march(Geo g, MarchStates<Phys> S, double dt, MarchBC bc, int* err, MarchSel sel,
+                                                               SourcePro pro, MarchTab tab) {
     static_assert(!TAB || (HAS_BC && !PRO), "face tables: blocks with physical faces, no source prologue");
+    static_assert(NT == 0 || (!PRO && !TAB), "passive scalars: no source prologue, no face tables");
+    constexpr int NTA = NT ? NT : 1;  // array lengths (no zero-length arrays)
     constexpr int RECON = Phys::RECON;
     static_assert(ReconTraits<RECON>::SL == 3 && Phys::IS_HYDRO, "three-point hydro reconstructions");
     dt = launch_dt(g, dt);  // device-resident time step (cmfp_advance_steps)
@@ -98,6 +106,22 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
         const long c = col + (long)row * g.sj;
 #pragma unroll
         for (int n = 0; n < 5; ++n) U[n] = Uin[c + n * g.sc];
+    };
+    auto load_row_tr = [&](int row, double* T) {
+        if constexpr (NT > 0) {
+            if (sel.wrap & 2) row = wrap_index(row, n1);
+            const long c = col + (long)row * g.sj;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) T[t] = Uin[c + (5 + t) * g.sc];
+        }
+    };
+    // alpha = tracer * rhoinv (MFP_thermally_perfect_gas.cpp:212-214)
+    auto to_alpha = [&](const double* U, const double* T, double* A) {
+        if constexpr (NT > 0) {
+            const double rhoinv = f_rcp(U[0]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) A[t] = T[t] * rhoinv;
+        }
     };
     // what stage A needs beside the species' own values: the other species' momentum, D and B
     auto load_row_pro = [&](int row, double* U) {
@@ -165,16 +189,22 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
     };
 
     double Qa[5], Qb[5], Un[NL];
+    double Aa[NTA], Ab[NTA], Tn[NTA];  // passive scalars: alpha of rows r - 1 and r, conserved tracers of row r + 1
     {
-        double U[NL];
+        double U[NL], T[NTA];
         load_row(ja - 2, U);
         load_row_pro(ja - 2, U);
+        load_row_tr(ja - 2, T);
+        to_alpha(U, T, Aa);
         to_prim(U, Qa, ja - 2);
         load_row(ja - 1, U);
         load_row_pro(ja - 1, U);
+        load_row_tr(ja - 1, T);
+        to_alpha(U, T, Ab);
         to_prim(U, Qb, ja - 1);
         load_row(ja, Un);
         load_row_pro(ja, Un);
+        load_row_tr(ja, Tn);
     }
     // carried from the previous iteration (row r - 1)
     double xlo_p[5], xhi_p[5];  // traced x-face states, not yet corrected
@@ -183,6 +213,10 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
     double fy_p[5], fy2_p[5];   // F_y and F'_y on the low y-face
 #pragma unroll
     for (int n = 0; n < 5; ++n) xlo_p[n] = xhi_p[n] = yhiU_p[n] = yhiC_p[n] = fy_p[n] = fy2_p[n] = 0.0;
+    // the same for the mass fractions and the tracer fluxes
+    double axlo_p[NTA], axhi_p[NTA], ayhiU_p[NTA], ayhiC_p[NTA], tfy_p[NTA], tfy2_p[NTA];
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) axlo_p[t] = axhi_p[t] = ayhiU_p[t] = ayhiC_p[t] = tfy_p[t] = tfy2_p[t] = 0.0;
     double red_speed = 2.2250738585072014e-308;  // std::numeric_limits<Real>::min(), MFP_eulerian.cpp:265
 
     // One row of the march.  The loop below runs it twice per trip: what a row hands to the next one then
@@ -190,10 +224,12 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
     // while row r + 1 computes its own); a trip past the last row (odd row count) computes and drops a row.
     auto march_row = [&](const int r) __attribute__((always_inline)) {
         const bool live = r <= jb + 1;
-        double Qc[5];
+        double Qc[5], Ac[NTA];
+        to_alpha(Un, Tn, Ac);
         to_prim(Un, Qc, r + 1 < jb + 2 ? r + 1 : jb + 2);
         const int rn = r + 2 < jb + 2 ? r + 2 : jb + 2;  // rows past the segment's stencil reach are not touched
         load_row(rn, Un);
+        load_row_tr(rn, Tn);
         double Uold[5];  // what the update of row r - 1 starts from (used once r - 1 >= ja)
         if constexpr (PRO) {
             // the stage-A values of row r - 1 from its primitives (eps = E - ke); contractions written out so that
@@ -207,10 +243,13 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
 #pragma unroll
             for (int n = 0; n < 5; ++n) Uold[n] = Uin[c + n * g.sc];
         }
+        double Told[NTA];
+        load_row_tr(r - 1, Told);
 
         // ---- reconstruction + half-step trace of row r (HydroState::calc_reconstruction,
         //      calc_time_averaged_faces)
         double xlo[5], xhi[5], ylo[5], yhi[5];
+        double axlo[NTA], axhi[NTA], aylo[NTA], ayhi[NTA];
         {
             double centre[5], speed[3];
 #pragma unroll
@@ -235,6 +274,21 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
             hydro_cell_faces<RECON>(gamma, st, ylo, yhi);
 #pragma unroll
             for (int n = 0; n < 5; ++n) trace_faces(speed[1], ky, centre[n], ylo[n], yhi[n]);
+            if constexpr (NT > 0) {  // alpha -+ slope / 2, traced like every primitive (MFP_hydro.cpp:982-995)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    double sa[3] = {lane_left(Ab[t]), Ab[t], lane_right(Ab[t])};
+                    double phi = recon_slope<RECON>(sa);
+                    axlo[t] = Ab[t] - 0.5 * phi;
+                    axhi[t] = Ab[t] + 0.5 * phi;
+                    trace_faces(speed[0], kx, Ab[t], axlo[t], axhi[t]);
+                    sa[0] = Aa[t], sa[2] = Ac[t];
+                    phi = recon_slope<RECON>(sa);
+                    aylo[t] = Ab[t] - 0.5 * phi;
+                    ayhi[t] = Ab[t] + 0.5 * phi;
+                    trace_faces(speed[1], ky, Ab[t], aylo[t], ayhi[t]);
+                }
+            }
         }
 
         if constexpr (TAB) {  // face_bc, do_all = false: the outside states of faces with Dirichlet data (valid face cells)
@@ -265,16 +319,29 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
         }
         // ---- Riemann sweep 1 on the low faces of (i, r)
         double fx[5], fy[5] = {0, 0, 0, 0, 0};
+        double tfx[NTA], tfy[NTA];
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) tfx[t] = tfy[t] = 0.0;
         {
             double L[5];
 #pragma unroll
             for (int n = 0; n < 5; ++n) L[n] = lane_left(xhi[n]);
-            Phys::riemann(P, 0, L, xlo, fx);
-            if (r >= ja) Phys::riemann(P, 1, yhiU_p, ylo, fy);
+            if constexpr (NT > 0) {
+                double aL[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) aL[t] = lane_left(axhi[t]);
+                Phys::template riemann_tracers<NT>(P, 0, L, xlo, aL, axlo, fx, tfx);
+                if (r >= ja) Phys::template riemann_tracers<NT>(P, 1, yhiU_p, ylo, ayhiU_p, aylo, fy, tfy);
+            } else {
+                Phys::riemann(P, 0, L, xlo, fx);
+                if (r >= ja) Phys::riemann(P, 1, yhiU_p, ylo, fy);
+            }
         }
-        double yhiU[5];
+        double yhiU[5], ayhiU[NTA];
 #pragma unroll
         for (int n = 0; n < 5; ++n) yhiU[n] = yhi[n];
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) ayhiU[t] = NT ? ayhi[t] : 0.0;
 
         // ---- transverse corrections (EulerianState::correct_face_prim MFP_eulerian.cpp:1047-1188,
         //      per cell: each face state is corrected with the transverse fluxes of its own cell)
@@ -283,16 +350,34 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
 #pragma unroll
             for (int n = 0; n < 5; ++n) dF[n] = fx[n] - lane_right(fx[n]);
             const bool col_in = inner && i >= 0 && i < n0;
-            const bool ok_hi = Phys::correct(P, yhi, kx, dF);
-            const bool ok_lo = Phys::correct(P, ylo, kx, dF);
+            bool ok_hi, ok_lo;
+            if constexpr (NT > 0) {
+                double dT[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dT[t] = tfx[t] - lane_right(tfx[t]);
+                ok_hi = Phys::template correct_tracers<NT>(P, yhi, ayhi, kx, dF, dT);
+                ok_lo = Phys::template correct_tracers<NT>(P, ylo, aylo, kx, dF, dT);
+            } else {
+                ok_hi = Phys::correct(P, yhi, kx, dF);
+                ok_lo = Phys::correct(P, ylo, kx, dF);
+            }
             if (live && col_in && ((!ok_hi && r < n1) || (!ok_lo && r >= 0 && r <= n1))) bad = true;
         }
         if (r > ja) {  // x-face states of row r - 1 use F_y(r - 1) - F_y(r)
             double dF[5];
 #pragma unroll
             for (int n = 0; n < 5; ++n) dF[n] = fy_p[n] - fy[n];
-            const bool ok_hi = Phys::correct(P, xhi_p, ky, dF);
-            const bool ok_lo = Phys::correct(P, xlo_p, ky, dF);
+            bool ok_hi, ok_lo;
+            if constexpr (NT > 0) {
+                double dT[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dT[t] = tfy_p[t] - tfy[t];
+                ok_hi = Phys::template correct_tracers<NT>(P, xhi_p, axhi_p, ky, dF, dT);
+                ok_lo = Phys::template correct_tracers<NT>(P, xlo_p, axlo_p, ky, dF, dT);
+            } else {
+                ok_hi = Phys::correct(P, xhi_p, ky, dF);
+                ok_lo = Phys::correct(P, xlo_p, ky, dF);
+            }
             const bool lane_ok = lane >= 1 && lane <= 62;
             if (live && lane_ok && ((!ok_hi && i >= -1 && i < n0) || (!ok_lo && i >= 0 && i <= n0))) bad = true;
         }
@@ -300,22 +385,36 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
         load_row_pro(rn, Un);  // requested here: half an iteration ahead is enough, and fewer values are live than at its start
         // ---- domain-face BCs (update_face_prim, do_all) + Riemann sweep 2
         double fy2[5] = {0, 0, 0, 0, 0};
+        double tfy2[NTA];
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) tfy2[t] = 0.0;
         if (r >= ja) {
-            double L[5], Rr[5];
+            double L[5], Rr[5], aL[NTA], aR[NTA];
 #pragma unroll
             for (int n = 0; n < 5; ++n) {
                 L[n] = yhiC_p[n];
                 Rr[n] = ylo[n];
             }
+#pragma unroll
+            for (int t = 0; t < NTA; ++t) {
+                aL[t] = ayhiC_p[t];
+                aR[t] = NT ? aylo[t] : 0.0;
+            }
             if (HAS_BC && bc.touch[1][0] && r == 0) {
 #pragma unroll
                 for (int n = 0; n < 5; ++n)
                     if (bc.rule[1][0][n]) L[n] = bc.rule[1][0][n] == FILL_ODD ? -Rr[n] : Rr[n];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (bc.rule[1][0][5 + t]) aL[t] = bc.rule[1][0][5 + t] == FILL_ODD ? -aR[t] : aR[t];
             }
             if (HAS_BC && bc.touch[1][1] && r == n1) {
 #pragma unroll
                 for (int n = 0; n < 5; ++n)
                     if (bc.rule[1][1][n]) Rr[n] = bc.rule[1][1][n] == FILL_ODD ? -L[n] : L[n];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (bc.rule[1][1][5 + t]) aR[t] = bc.rule[1][1][5 + t] == FILL_ODD ? -aL[t] : aL[t];
             }
             if constexpr (TAB) {
                 if (i >= 0 && i < n0) {
@@ -331,24 +430,39 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
                     }
                 }
             }
-            Phys::riemann(P, 1, L, Rr, fy2);
+            if constexpr (NT > 0)
+                Phys::template riemann_tracers<NT>(P, 1, L, Rr, aL, aR, fy2, tfy2);
+            else
+                Phys::riemann(P, 1, L, Rr, fy2);
         }
         if (r > ja) {
-            double L[5], Rr[5], fx2[5];
+            double L[5], Rr[5], fx2[5], aL[NTA], aR[NTA], tfx2[NTA];
 #pragma unroll
             for (int n = 0; n < 5; ++n) {
                 L[n] = lane_left(xhi_p[n]);
                 Rr[n] = xlo_p[n];
             }
+#pragma unroll
+            for (int t = 0; t < NTA; ++t) {
+                aL[t] = NT ? lane_left(axhi_p[t]) : 0.0;
+                aR[t] = axlo_p[t];
+                tfx2[t] = 0.0;
+            }
             if (HAS_BC && bc.touch[0][0] && i == 0) {
 #pragma unroll
                 for (int n = 0; n < 5; ++n)
                     if (bc.rule[0][0][n]) L[n] = bc.rule[0][0][n] == FILL_ODD ? -Rr[n] : Rr[n];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (bc.rule[0][0][5 + t]) aL[t] = bc.rule[0][0][5 + t] == FILL_ODD ? -aR[t] : aR[t];
             }
             if (HAS_BC && bc.touch[0][1] && i == n0) {
 #pragma unroll
                 for (int n = 0; n < 5; ++n)
                     if (bc.rule[0][1][n]) Rr[n] = bc.rule[0][1][n] == FILL_ODD ? -L[n] : L[n];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (bc.rule[0][1][5 + t]) aR[t] = bc.rule[0][1][5 + t] == FILL_ODD ? -aL[t] : aL[t];
             }
             if constexpr (TAB) {
                 if (r - 1 >= 0 && r - 1 < n1) {
@@ -364,9 +478,12 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
                     }
                 }
             }
-            Phys::riemann(P, 0, L, Rr, fx2);
+            if constexpr (NT > 0)
+                Phys::template riemann_tracers<NT>(P, 0, L, Rr, aL, aR, fx2, tfx2);
+            else
+                Phys::riemann(P, 0, L, Rr, fx2);
             // ---- divergence of row r - 1 (calc_divergence MFP_eulerian.cpp:1614-1662), new += dU
-            double Unew[5];
+            double Unew[5], Tnew[NTA];
 #pragma unroll
             for (int n = 0; n < 5; ++n) {
                 const double fxh = lane_right(fx2[n]);
@@ -375,10 +492,20 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
                 du += dtdy * (fy2_p[n] - fy2[n]);
                 Unew[n] = Uold[n] + du;
             }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double fxh = lane_right(tfx2[t]);
+                double du = 0.0;
+                du += dtdx * (tfx2[t] - fxh);
+                du += dtdy * (tfy2_p[t] - tfy2[t]);
+                Tnew[t] = Told[t] + du;
+            }
             if (upd && live) {
                 const long c = col + (long)(r - 1) * g.sj;
 #pragma unroll
                 for (int n = 0; n < 5; ++n) Uout[c + n * g.sc] = Unew[n];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) Uout[c + (5 + t) * g.sc] = Tnew[t];
                 if constexpr (REDUCE) {  // EulerianState::get_allowed_time_step MFP_eulerian.cpp:290-296
                     double s[3];
                     hydro_speed_from_cons(P.gas, Unew, s);
@@ -396,6 +523,17 @@ __global__ __launch_bounds__(64, 2) void k_ctu_march(Geo g, MarchStates<Phys> S,
             yhiC_p[n] = yhi[n];
             fy_p[n] = fy[n];
             fy2_p[n] = fy2[n];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            Aa[t] = Ab[t];
+            Ab[t] = Ac[t];
+            axlo_p[t] = axlo[t];
+            axhi_p[t] = axhi[t];
+            ayhiU_p[t] = ayhiU[t];
+            ayhiC_p[t] = ayhi[t];
+            tfy_p[t] = tfy[t];
+            tfy2_p[t] = tfy2[t];
         }
     };
     for (int r = ja - 1; r <= jb + 1; r += 2) {
@@ -429,6 +567,11 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
 #endif
     }
     if (tabs && (n != 1 || !has_bc || pro)) return 0;  // Dirichlet face data: one state, a block with physical faces, no prologue
+    // passive scalars (species of equal mass / gamma): their own kernel instances; true mixtures (per-cell gamma), the
+    // hybrid flux (no tracer flux in the reference, Q5), the prologue and face tables stay outside
+    const int nt = sp[0]->hp.nt;
+    if (nt && (sp[0]->hp.mix || Phys::FLUX == 2 || pro || tabs || nt > 2)) return 0;
+    if (n == 2 && sp[1]->hp.nt != nt) return 0;
     if (!Uin[0]) return part == 1 ? has_int : 1;
     const MarchBC bc = make_march_bc(*sp[0], touches);
     MarchStates<Phys> S;
@@ -452,6 +595,19 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
         else
             hipLaunchKernelGGL((k_ctu_march<Phys, true, false, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb);
         return 1;
+    }
+    if constexpr (Phys::FLUX != 2) {
+        if (nt) {  // (always the instance with the face rules: half as many kernels to build)
+#define CMFP_LAUNCH_T(RED, NTV) \
+    hipLaunchKernelGGL((k_ctu_march<Phys, true, RED, false, false, NTV>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb)
+            if (red[0]) {
+                if (nt == 1) CMFP_LAUNCH_T(true, 1); else CMFP_LAUNCH_T(true, 2);
+            } else {
+                if (nt == 1) CMFP_LAUNCH_T(false, 1); else CMFP_LAUNCH_T(false, 2);
+            }
+#undef CMFP_LAUNCH_T
+            return 1;
+        }
     }
 #define CMFP_LAUNCH(BC, RED) hipLaunchKernelGGL((k_ctu_march<Phys, BC, RED, false>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb)
 #ifdef CMFP_FASTMATH

@@ -491,8 +491,9 @@ def _band(d):
 @pytest.mark.parametrize("flux,scheme,recon", [("HLLC", "strang", "vanLeer"), ("HLLE", "strang", "minmod"),
                                                 ("HLLC", "RK2", "MC"), ("HLLC", "euler", "O6")])
 def test_tracers_parity_2d(oracle, flux, scheme, recon):
-    """hydro state with two passive scalars (stage-by-stage kernels): STRICT bit-identical to the
-    oracle, FAST within 1e-12, walls in y (scalar ghost rule on the tracer comps)."""
+    """hydro state with two passive scalars: STRICT bit-identical to the oracle, FAST within 1e-12, walls in y (scalar
+    ghost rule on the tracer comps).  Strang steps with a three-point limiter run on the marching kernel's tracer
+    instances (k_ctu_march<..., NT>), and once more on the stage-by-stage kernels; euler / RK2 / O6 stage by stage."""
     for walls in (False, True):
         cfg = _kh(recon, flux, scheme)
         if walls:
@@ -504,15 +505,45 @@ def test_tracers_parity_2d(oracle, flux, scheme, recon):
             P = config.Problem(cfg, fp_mode=mode)
             ref = oracle.OracleSim(P)
             dts_ref = ref.run(5)
-            m = _gpu(P)
-            dts = m.run(5)
-            assert m.last_advance_path() == 0
+            for fused in ((True, False) if scheme == "strang" else (True,)):
+                m = _gpu(P, fused=fused)
+                dts = m.run(5)
+                assert m.last_advance_path() == (1 if scheme == "strang" and fused else 0)
+                if tol == 0.0:
+                    assert dts == dts_ref
+                assert rel_linf(m.download(0), ref.get_state(0)) <= tol, (walls, mode, fused)
+                for c in (5, 6):
+                    assert rel_linf(m.download(0)[c], ref.get_state(0)[c]) <= tol, (walls, mode, c, fused)
+                if tol == 0.0:
+                    assert np.array_equal(m.download(0), ref.get_state(0)), (walls, fused)
+                m.close()
+
+
+@pytest.mark.parametrize("n,nt", [((150, 70), 2), ((64, 131), 1), ((61, 9), 1)])
+def test_tracers_on_the_marching_kernel_at_size(oracle, n, nt):
+    """several strips and segments, block sizes off the 60-column strips, one and two passive scalars, outflow faces
+    in x and periodic y (the in-kernel wrap), two species in one launch with the plasma5 source beside them: STRICT
+    bit-identical to the oracle, FAST within 1e-12, path 1."""
+    cfg = problems.orszag_tang_two_fluid_2d(64)
+    cfg["n_cell"] = list(n)
+    cfg["is_periodic"] = [0, 1]
+    al = [lambda d: 0.5 + 0.25 * np.sin(d["x"]) * np.cos(2 * d["y"]), lambda d: 0.1 + 0.05 * np.cos(d["x"])][:nt]
+    for name in ("ion", "electron"):
+        problems.with_tracers(cfg, name, al)
+    for mode, tol in ((abi.FP_STRICT, 0.0), (abi.FP_FAST, 1e-12)):
+        P = config.Problem(cfg, fp_mode=mode)
+        ref = oracle.OracleSim(P)
+        dts_ref = ref.run(4)
+        m = _gpu(P)
+        dts = m.run(4)
+        assert m.last_advance_path() == 1
+        for s in range(3):
+            a, b = m.download(s), ref.get_state(s)
             if tol == 0.0:
-                assert dts == dts_ref
-            assert rel_linf(m.download(0), ref.get_state(0)) <= tol, (walls, mode)
-            for c in (5, 6):
-                assert rel_linf(m.download(0)[c], ref.get_state(0)[c]) <= tol, (walls, mode, c)
-            m.close()
+                assert dts == dts_ref and np.array_equal(a, b), (n, nt, P.state_names[s])
+            else:
+                assert rel_linf(a, b) <= tol, (n, nt, P.state_names[s])
+        m.close()
 
 
 def test_tracers_two_fluid_and_3d(oracle):
