@@ -941,7 +941,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
         }
         if (!ok) epi_q = -1;
     }
-    // Strang stage A as the prologue of the marching kernels (mfp_source.h): FAST arithmetic, 2-D, the two species
+    // Strang stage A as the prologue of the marching kernels (mfp_source.h): 2-D, the two species
     // of an explicit plasma5 / Lorentz action in one paired hydro launch, the field on the marching vacuum kernel
     // with stage C as its epilogue; physical faces where their ghost cells are signed copies of one valid cell.
     // Then no kernel of the step rewrites a state in
@@ -949,7 +949,7 @@ int advance_strang_fused(cmfp_context* c, double dt, bool reserve_only = false) 
     // to what they load.
     SourcePro pro;
     std::memset(&pro, 0, sizeof(pro));
-    if (epi_q >= 0 && c->src_prologue && c->params.fp_mode == CMFP_FP_FAST && c->g.dim == 2 && epi.ns == 2 && !tile_flag &&
+    if (epi_q >= 0 && c->src_prologue && c->g.dim == 2 && epi.ns == 2 && !tile_flag &&
         list.size() == 3 && !any_tables) {  // (ghost cells with Dirichlet data are not copies of valid cells)
         const cmfp_action_desc& SA = c->actions[src];
         size_t qs[2] = {0, 0};
@@ -1483,7 +1483,7 @@ int cmfp_create(const cmfp_geometry* geom, const cmfp_params* params, int n_stat
     // Where the source prologue may run (decided per step in advance_strang_fused; the conditions that do not
     // change are checked here) the field's kernel evaluates stage A from the species' values over its own stencil
     // reach: their ghost layers are kept current to the field's width
-    if (c->src_prologue && params->fp_mode == CMFP_FP_FAST && geom->dim == 2 && params->time_integrator == CMFP_TI_STRANG)
+    if (c->src_prologue && geom->dim == 2 && params->time_integrator == CMFP_TI_STRANG)
         for (const auto& A : c->actions)
             if ((A.kind == CMFP_ACTION_LORENTZ || (A.kind == CMFP_ACTION_PLASMA5 && A.solver != CMFP_SOLVER_IMPLICIT)) && A.n_states == 3)
                 for (int i = 0; i < 2; ++i) {

@@ -43,7 +43,8 @@ struct MarchStates {
 // PRO: Strang source stage A (explicit plasma5 / Lorentz over the launch's two species) applied to every row as
 // it is loaded (SourcePro, mfp_source.h): the wave also reads the other species' momentum and D, B of the field
 // (14 values per cell instead of 5) and the stage-A values a row's update starts from are rebuilt from its
-// primitives instead of being read again.  FAST arithmetic only.
+// primitives instead of being read again (FAST; STRICT carries the conserved stage-A values of two rows instead, which
+// keeps the update bit-identical to the separate launch).
 // TAB: Dirichlet data on physical faces (MarchTab): the ghost cells beyond such a face get the tabulated primitives
 // in place of their own (EulerianState::update_boundary_cells MFP_eulerian.cpp:435-511), the outside face states the
 // values at the face centres, once before sweep 1 — kept, like the reference keeps them in its face arrays — and
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(64, NT ? 1 : 2) void k_ctu_march(Geo g, MarchStates
 
     double Qa[5], Qb[5], Un[NL];
     double Aa[NTA], Ab[NTA], Tn[NTA];  // passive scalars: alpha of rows r - 1 and r, conserved tracers of row r + 1
+    double Sa[5], Sb[5];               // STRICT with the prologue: conserved stage-A values of rows r - 1 and r
     {
         double U[NL], T[NTA];
         load_row(ja - 2, U);
@@ -197,11 +199,15 @@ __global__ __launch_bounds__(64, NT ? 1 : 2) void k_ctu_march(Geo g, MarchStates
         load_row_tr(ja - 2, T);
         to_alpha(U, T, Aa);
         to_prim(U, Qa, ja - 2);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) Sa[n] = U[n];
         load_row(ja - 1, U);
         load_row_pro(ja - 1, U);
         load_row_tr(ja - 1, T);
         to_alpha(U, T, Ab);
         to_prim(U, Qb, ja - 1);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) Sb[n] = U[n];
         load_row(ja, Un);
         load_row_pro(ja, Un);
         load_row_tr(ja, Tn);
@@ -227,17 +233,30 @@ __global__ __launch_bounds__(64, NT ? 1 : 2) void k_ctu_march(Geo g, MarchStates
         double Qc[5], Ac[NTA];
         to_alpha(Un, Tn, Ac);
         to_prim(Un, Qc, r + 1 < jb + 2 ? r + 1 : jb + 2);
+#ifndef CMFP_FASTMATH
+        double Sc[5];  // (PRO) row r + 1 after stage A, conserved
+        if constexpr (PRO) {
+#pragma unroll
+            for (int n = 0; n < 5; ++n) Sc[n] = Un[n];
+        }
+#endif
         const int rn = r + 2 < jb + 2 ? r + 2 : jb + 2;  // rows past the segment's stencil reach are not touched
         load_row(rn, Un);
         load_row_tr(rn, Tn);
         double Uold[5];  // what the update of row r - 1 starts from (used once r - 1 >= ja)
         if constexpr (PRO) {
+#ifdef CMFP_FASTMATH
             // the stage-A values of row r - 1 from its primitives (eps = E - ke); contractions written out so that
             // both copies of this row pipeline round alike
 #pragma clang fp contract(off)
             const double q2 = fma(Qa[H_W], Qa[H_W], fma(Qa[H_V], Qa[H_V], Qa[H_U] * Qa[H_U]));
             Uold[0] = Qa[H_RHO], Uold[1] = Qa[H_U] * Qa[H_RHO], Uold[2] = Qa[H_V] * Qa[H_RHO], Uold[3] = Qa[H_W] * Qa[H_RHO];
             Uold[4] = fma(0.5 * Qa[H_RHO], q2, Qa[H_P]);
+#else
+            // STRICT: the conserved stage-A values themselves, carried from the iteration that converted the row
+#pragma unroll
+            for (int n = 0; n < 5; ++n) Uold[n] = Sa[n];
+#endif
         } else {
             const long c = col + (long)(r - 1) * g.sj;
 #pragma unroll
@@ -524,6 +543,15 @@ __global__ __launch_bounds__(64, NT ? 1 : 2) void k_ctu_march(Geo g, MarchStates
             fy_p[n] = fy[n];
             fy2_p[n] = fy2[n];
         }
+#ifndef CMFP_FASTMATH
+        if constexpr (PRO) {
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                Sa[n] = Sb[n];
+                Sb[n] = Sc[n];
+            }
+        }
+#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             Aa[t] = Ab[t];
@@ -559,12 +587,8 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
     sel.wrap = part_wrap(part);
     part &= 0xff;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1] || g.bc_instance;
-    if (pro) {  // the prologue: FAST build, both species in the launch, stage C follows (no reduction here)
-#ifdef CMFP_FASTMATH
+    if (pro) {  // the prologue: both species in the launch, stage C follows (no reduction here)
         if (n != 2 || red[0]) return 0;
-#else
-        return 0;
-#endif
     }
     if (tabs && (n != 1 || !has_bc || pro)) return 0;  // Dirichlet face data: one state, a block with physical faces, no prologue
     // passive scalars (species of equal mass / gamma): their own kernel instances; true mixtures (per-cell gamma), the
@@ -610,7 +634,6 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
         }
     }
 #define CMFP_LAUNCH(BC, RED) hipLaunchKernelGGL((k_ctu_march<Phys, BC, RED, false>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb)
-#ifdef CMFP_FASTMATH
     if (pro) {
         pr = *pro;
         if (has_bc)
@@ -619,7 +642,6 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
             hipLaunchKernelGGL((k_ctu_march<Phys, false, false, true>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb);
         return 1;
     }
-#endif
     if (red[0]) {
         if (has_bc) CMFP_LAUNCH(true, true); else CMFP_LAUNCH(false, true);
     } else {

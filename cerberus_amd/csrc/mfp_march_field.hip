@@ -404,12 +404,8 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
     if (g.ng[0] < 4 || g.ng[1] < 4 || g.n[0] < 1 || g.n[1] < 1) return 0;
     if (epi && (epi->a.implicit || epi->a.coll.on || epi->ns < 1 || epi->ns > 2)) return 0;
     const bool has_bc = touches[0][0] || touches[0][1] || touches[1][0] || touches[1][1] || g.bc_instance;
-    if (pro) {  // source stage A as the prologue: FAST build, two species with the epilogue
-#ifdef CMFP_FASTMATH
+    if (pro) {  // source stage A as the prologue: two species with the epilogue
         if (!epi || epi->ns != 2) return 0;
-#else
-        return 0;
-#endif
     }
     if (!Uin) return 1;  // coverage probe
     MarchSel sel;
@@ -440,7 +436,6 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
     SourcePro pr;
     std::memset(&pr, 0, sizeof(pr));
 #define FLD(BC, NS, E) hipLaunchKernelGGL((k_fld_march<BC, NS, false>), grid, block, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, E, pr)
-#ifdef CMFP_FASTMATH
     if (pro) {
         pr = *pro;
         if (has_bc)
@@ -449,7 +444,6 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
             hipLaunchKernelGGL((k_fld_march<false, 2, true>), grid, block, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, *epi, pr);
         return 1;
     }
-#endif
     if (epi && epi->ns == 2) {
         if (has_bc) FLD(true, 2, *epi); else FLD(false, 2, *epi);
     } else if (epi && epi->ns == 1) {

@@ -195,8 +195,7 @@ CMFP_DEV void source_rk2_explicit_cell(const Args& a, const SourceCoef& kf, doub
     fnew[4] = half_sum(f0[F_PSI], f1[F_PSI] + fdU[4]);
 }
 
-// ---- Strang source stage A as the prologue of the CTU kernels (FAST arithmetic, 2-D, explicit plasma5 /
-// Lorentz over two species, block without physical faces).  Stage A (MFP_advance.cpp:146-197) is pointwise, so a
+// ---- Strang source stage A as the prologue of the CTU kernels (2-D, explicit plasma5 / Lorentz over two species).  Stage A (MFP_advance.cpp:146-197) is pointwise, so a
 // CTU kernel can apply it to every cell it loads — ghost cells included: a periodic or neighbour copy of the raw
 // values gives the same result as the copy of the result — instead of a launch of its own that reads and
 // rewrites all states.  Each kernel evaluates what its state needs of the coupled RK2 (a species: its own
@@ -256,6 +255,11 @@ CMFP_DEV void source_prologue_species(const ProArgs& a, const SourceCoef& kf, do
     source_rk2_explicit_cell<2>(a, kf, hdt, f0, s0, fnew, snew);
 #pragma unroll
     for (int n = 0; n < 4; ++n) own[n + 1] = snew[0][n];
+#ifndef CMFP_FASTMATH
+    // the density, which no source term touches: the reference's LinComb 0.5 x + 0.5 x, which is x except for
+    // subnormal values with an odd last bit (see k_source_rk2)
+    own[0] = 0.5 * own[0] + 0.5 * own[0];
+#endif
 }
 // A field wave: f = {Dx, Dy, Dz, Bx, By, Bz, phi, psi} (in/out); sa, sb = {rho, mx, my, mz} of the two species
 CMFP_DEV void source_prologue_field(const ProArgs& a, const SourceCoef& kf, double hdt, double* f, const double* sa,
@@ -266,6 +270,10 @@ CMFP_DEV void source_prologue_field(const ProArgs& a, const SourceCoef& kf, doub
     double fnew[5], snew[2][4];
     source_rk2_explicit_cell<2>(a, kf, hdt, f0, s0, fnew, snew);
     f[F_DX] = fnew[0], f[F_DY] = fnew[1], f[F_DZ] = fnew[2], f[F_PHI] = fnew[3], f[F_PSI] = fnew[4];
+#ifndef CMFP_FASTMATH
+#pragma unroll
+    for (int n : {F_BX, F_BY, F_BZ}) f[n] = 0.5 * f[n] + 0.5 * f[n];  // as above (mu = ep = 1 on a vacuum block: exact)
+#endif
 }
 
 // kernel argument of the source epilogue (SRC species; nothing without one)

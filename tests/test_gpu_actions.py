@@ -719,7 +719,9 @@ def test_source_epilogue(oracle, monkeypatch, name, make):
         m.profile_read(2)
         dts = m.run(4)
         launches, _ = m.profile_read(2)
-        assert launches == (4 if epilogue else 8), (name, epilogue, launches)
+        # with the epilogue the 2-D steps also take stage A as the prologue of the marching kernels (STRICT since
+        # round 3): no source launch at all; 3-D keeps stage A a launch
+        assert launches == ((0 if P.dim == 2 else 4) if epilogue else 8), (name, epilogue, launches)
         assert dts == dts_ref, (name, epilogue)
         for s in range(len(P.state_names)):
             assert np.array_equal(m.download(s), ref.get_state(s)), (name, epilogue, P.state_names[s])
@@ -730,7 +732,7 @@ def test_source_epilogue_with_split_launches_and_mixed_stencils(oracle):
     """forced split launches (overlap=2): with three-point species and an O6 field the field's interior
     launch carries the source epilogue on the second stream (its interior lies inside the species'
     interiors); with O6 species the hydro states leave the tiled kernels, nothing is split and the epilogue
-    follows whole launches.  Bit-identical to the oracle either way, one source launch per step."""
+    follows whole launches.  Bit-identical to the oracle either way, at most one source launch per step."""
     for hydro_recon, field_recon in (("O6", "minmod"), ("minmod", "O6"), ("vanLeer", "minmod")):
         cfg = problems.orszag_tang_two_fluid_2d(96)
         for name in ("ion", "electron"):
@@ -744,7 +746,9 @@ def test_source_epilogue_with_split_launches_and_mixed_stencils(oracle):
         m.profile_read(2)
         dts = m.run(3)
         launches, _ = m.profile_read(2)
-        assert launches == 3, (hydro_recon, field_recon, launches)
+        # (minmod species with the O6 vacuum field: the marching kernels, which since round 3 also take stage A as
+        # their prologue in STRICT arithmetic: no source launch at all)
+        assert launches == (0 if (hydro_recon, field_recon) == ("minmod", "O6") else 3), (hydro_recon, field_recon, launches)
         assert dts == dts_ref
         for s in range(3):
             assert np.array_equal(m.download(s), ref.get_state(s)), (hydro_recon, field_recon, P.state_names[s])
