@@ -117,7 +117,8 @@ struct cmfp_context {
     struct PeerRT {
         bool enabled = false;
         int rank = -1, world = 0;
-        char* arena = nullptr;                         // this rank's arena (hipMalloc)
+        char* arena = nullptr;                         // this rank's arena (fine-grained device memory)
+        bool fine = false;
         char* remote[cmfp_peer::MAX_RANKS] = {};       // every rank's arena as this process sees it; remote[rank] = arena
         bool opened[cmfp_peer::MAX_RANKS] = {};        // mapped with hipIpcOpenMemHandle: closed by cmfp_destroy
         int nb[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}}; // neighbour rank of face (d, side), -1: none
@@ -2142,7 +2143,21 @@ int cmfp_peer_init(cmfp_context* c, int rank, int world, void* ipc_handle_out, v
     P.world = world;
     if (const char* e = std::getenv("CMFP_PEER_TIMEOUT")) P.timeout_s = std::max(0.05, std::atof(e));
     peer_layout(c);
-    HIPCHK(c, hipMalloc((void**)&P.arena, P.L.bytes));
+    // Fine-grained device memory: the progress words and slots are written by kernels of other processes / devices
+    // while this device's kernels poll them, which ordinary (coarse-grained) allocations only promise to make
+    // visible at kernel boundaries.  CMFP_PEER_COARSE=1 (or a runtime without the flag): plain hipMalloc.
+    static const bool coarse = std::getenv("CMFP_PEER_COARSE") && std::atoi(std::getenv("CMFP_PEER_COARSE")) != 0;
+    if (coarse || hipExtMallocWithFlags((void**)&P.arena, P.L.bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        P.arena = nullptr;
+        HIPCHK(c, hipMalloc((void**)&P.arena, P.L.bytes));
+        P.fine = false;
+    } else {
+        P.fine = true;
+    }
+    if (std::getenv("CMFP_PEER_DEBUG"))
+        std::fprintf(stderr, "cmfp_peer_init: rank %d of %d, arena %zu bytes, %s memory\n", rank, world, (size_t)P.L.bytes,
+                     P.fine ? "fine-grained" : "coarse-grained");
     HIPCHK(c, hipMemsetAsync(P.arena, 0, P.L.bytes, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the words are zero before any neighbour can learn the address
     P.remote[rank] = P.arena;

@@ -56,7 +56,7 @@ struct MarchStates {
 // alpha = tracer / rho' (prim2cons / cons2prim, MFP_thermally_perfect_gas.cpp:212-214,243-245).  These instances
 // hold about 60 more values per lane and run at one wave per SIMD.
 template <class Phys, bool HAS_BC, bool REDUCE, bool PRO, bool TAB = false, int NT = 0>
-__global__ __launch_bounds__(64, NT ? 1 : 2) void k_ctu_march(Geo g, MarchStates<Phys> S, double dt, MarchBC bc, int* err, MarchSel sel,
+__global__ __launch_bounds__(64, (NT || (PRO && Phys::FLUX == 2)) ? 1 : 2) void k_ctu_march(Geo g, MarchStates<Phys> S, double dt, MarchBC bc, int* err, MarchSel sel,
                                                                SourcePro pro, MarchTab tab) {
     static_assert(!TAB || (HAS_BC && !PRO), "face tables: blocks with physical faces, no source prologue");
     static_assert(NT == 0 || (!PRO && !TAB), "passive scalars: no source prologue, no face tables");
@@ -704,7 +704,9 @@ int ctu_march2(const Geo& g, const StatePhys* const sp[2], const double* const U
     if (std::memcmp(a.bc, b.bc, sizeof(a.bc)) != 0) return 0;
     static const bool off = std::getenv("CMFP_MARCH_PAIR") && std::atoi(std::getenv("CMFP_MARCH_PAIR")) == 0;
     if (off) return 0;
-    if (pro && a.flux == 2) return 0;  // the hybrid HLLE/HLLC kernel with the prologue does not fit two waves per SIMD
+    // (the hybrid HLLE/HLLC kernel with the prologue does not fit two waves per SIMD: that instance runs at one)
+    static const bool hyb_pro = !(std::getenv("CMFP_HYBRID_PROLOGUE") && std::atoi(std::getenv("CMFP_HYBRID_PROLOGUE")) == 0);
+    if (pro && a.flux == 2 && !hyb_pro) return 0;
 #define HY(R, F) \
     if (a.recon == R && a.flux == F) return launch_march<HydroF<R, F>>(g, 2, sp, Uin, Uout, dt, touches, err, red, part, pro, st);
     HY(1, 0) HY(1, 1) HY(1, 2) HY(2, 0) HY(2, 1) HY(2, 2) HY(3, 0) HY(3, 1) HY(4, 0) HY(4, 1)

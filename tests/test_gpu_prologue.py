@@ -101,6 +101,29 @@ def test_strict_prologue_is_bit_identical(oracle, shape, steps, source, faces):
     b.close()
 
 
+@pytest.mark.parametrize("mode", [abi.FP_STRICT, abi.FP_FAST], ids=["strict", "fast"])
+@pytest.mark.parametrize("faces", ["pp", "pw"])
+def test_prologue_with_the_hybrid_flux(oracle, mode, faces):
+    """HLLE/HLLC with the pressure-jump detector: the prologue instance of the hydro kernel runs at one wave per SIMD
+    (it does not fit two); STRICT bit-identical to the oracle, FAST within the north-star bound"""
+    cfg = _ot(130, 70, faces=faces)
+    for n in ("ion", "electron"):
+        cfg["states"][n]["flux"] = "HLLE/HLLC"
+        cfg["states"][n]["shock_detector"] = {"name": "pressure_jump_detector", "threshold": 0.3}
+    P = config.Problem(cfg, fp_mode=mode)
+    ref = oracle.OracleSim(P, max_grid_size=32)
+    dts_ref = ref.run(6)
+    a = _gpu(P)
+    da = a.run(6)
+    assert a.last_advance_path() == 1 and a.last_source_fusion() == 3
+    for s in range(a.n_states):
+        if mode == abi.FP_STRICT:
+            assert da == dts_ref and np.array_equal(a.download(s), ref.get_state(s)), P.state_names[s]
+        else:
+            assert rel_linf(a.download(s), ref.get_state(s)) <= TOL_FAST, (P.state_names[s], rel_linf(a.download(s), ref.get_state(s)))
+    a.close()
+
+
 def test_strict_prologue_with_denormal_components(oracle):
     """components the source does not touch pass through the reference's 0.5 x + 0.5 x (MFP_advance.cpp:194), which
     changes a subnormal value with an odd last bit: the prologue does the same (rho of the species, B of the field)"""
