@@ -367,6 +367,347 @@ __global__ __launch_bounds__(64, 1) void k_fld_march(Geo g, FieldParams P, const
     }
 }
 
+// ---- The same update by a pair of waves per strip (round 3).  In two dimensions the vacuum Maxwell system with its
+// cleaning potentials splits into two sets of four components that never meet in a flux: TE = {Dx, Dy, Bz, phi} and
+// TM = {Dz, Bx, By, psi} (x faces pair (Dy, Bz), (Dz, By), (Dx, phi), (Bx, psi); y faces (Dz, Bx), (Dx, Bz), (Dy, phi),
+// (By, psi): every pair lies inside one set).  k_fld_march carries all eight through one wave: 400 registers, one
+// wave per SIMD, and a wave alone cannot cover its own instruction latencies (VALU active 58 % of its cycles).  Here a
+// workgroup of two waves owns the strip: wave G runs interfaces, traces, Riemann sweeps, corrections and the
+// divergence for its four components (half the registers: two waves per SIMD), and what couples the sets — source
+// stage A on the rows that enter the window, stage C on the rows that leave — alternates between the two waves row
+// by row through LDS, so no arithmetic is done twice.  Per value the same device functions in the same order as
+// k_fld_march (the other set's slots of a Riemann solve hold zeros, and the compiler drops what only they feed).
+// Result (4096^2 with prologue and epilogue, A/B on one box): 235 - 256 VGPRs, 28.8 KB of LDS per pair, bit-identical
+// results, and 1.60 ms against 1.43 ms for k_fld_march — the launch moves 6.2 GB at 4.3 TB/s, 83 % of what a copy
+// kernel reaches on this device, so it is the memory system and not the lone wave's latencies that bounds it, and the
+// pair adds two barriers per row to that.  Kept selectable (CMFP_FIELD_PAIR=1) and tested; not the default.
+CMFP_DEV constexpr int fgc(int G, int q) {  // component q of set G
+    return G == 0 ? (q == 0 ? F_DX : q == 1 ? F_DY : q == 2 ? F_BZ : F_PHI) : (q == 0 ? F_DZ : q == 1 ? F_BX : q == 2 ? F_BY : F_PSI);
+}
+CMFP_DEV constexpr int fgrp(int n) { return (n == F_DX || n == F_DY || n == F_BZ || n == F_PHI) ? 0 : 1; }
+CMFP_DEV constexpr int fidx(int n) {
+    return n == F_DX ? 0 : n == F_DY ? 1 : n == F_BZ ? 2 : n == F_PHI ? 3 : n == F_DZ ? 0 : n == F_BX ? 1 : n == F_BY ? 2 : 3;
+}
+template <int G> struct FldSet { static constexpr int value = G; };
+
+template <bool HAS_BC, int SRC, bool PRO>
+__global__ __launch_bounds__(128, 2) void k_fld_pair(Geo g, FieldParams P, const double* __restrict__ Uin, double* __restrict__ Uout,
+                                                      double dt, MarchBC bc, MarchSel sel, typename EpiArg<SRC>::type epi, SourcePro pro) {
+    typedef FieldF<5> Phys;
+    constexpr int RG = FLD_NR * 4 * 64;  // one set's window
+    __shared__ double ring_[2 * RG + 2 * FLD_PAD + 8 * 64];
+    double* const ring = ring_ + FLD_PAD;
+    double* const xchg = ring + 2 * RG + FLD_PAD;  // the updated row, all eight components, for stage C
+    dt = launch_dt(g, dt);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per = (sel.nwaves + 7) >> 3;  // XCD-aware order: neighbouring strips on one XCD
+    const int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    double src_speed[SRC > 0 ? SRC : 1];
+    SrcDt src_dt;
+#pragma unroll
+    for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s) src_speed[s] = DBL_MIN;
+    if (w < sel.nwaves) {
+        const MarchRect R = sel.r[0];
+        const int segi = w / R.ns, strip = w - segi * R.ns;
+        const int n0 = g.n[0], n1 = g.n[1];
+        const int i = R.ilo + strip * FLD_MW - 4 + lane;
+        int ic = i < R.ihi + 4 ? i : R.ihi + 4;
+        if (sel.wrap & 1) ic = wrap_index(ic, n0);
+        const int ja = R.jlo + segi * sel.seg;
+        const int jb = (ja + sel.seg - 1 < R.jhi) ? ja + sel.seg - 1 : R.jhi;
+        const bool upd = lane >= 4 && lane <= 59 && i <= R.ihi;
+        const double speed = P.fastest;
+        const double hx = uni(0.5 * dt / g.dx[0]), hy = uni(0.5 * dt / g.dx[1]);
+        const double dtdx = uni(dt / g.dx[0]), dtdy = uni(dt / g.dx[1]);
+        const long col = g.at(ic, 0, 0);
+        const int row0 = ja - 4;
+        double mlo[2], mhi[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#ifdef CMFP_FASTMATH
+            mlo[d] = mhi[d] = 1.0;
+#else
+            const double flat[7] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+            recon_faces<5>(flat, mlo[d], mhi[d]);
+            trace_faces(speed, d == 0 ? hx : hy, 1.0, mlo[d], mhi[d]);
+#endif
+        }
+        constexpr int NL = PRO ? 16 : 8;
+        const double* __restrict__ Sa = PRO ? pro.sp[0] : nullptr;
+        const double* __restrict__ Sb = PRO ? pro.sp[1] : nullptr;
+        const ProArgs pa = pro_args(pro, 0);
+        const double hdt = 0.5 * dt;
+        const SourceCoef kf = source_coef(pa, hdt);
+        auto load_row = [&](int row, double* U) {
+            if (sel.wrap & 2) row = wrap_index(row, n1);
+            const long c = col + (long)row * g.sj;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) U[n] = Uin[c + n * g.sc];
+            if constexpr (PRO) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) U[8 + n] = Sa[c + n * g.sc];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) U[12 + n] = Sb[c + n * g.sc];
+            }
+        };
+        auto enter = [&](double* U, int row) {
+            if constexpr (PRO) {
+                ProMask m{0u, 0u};
+                bool any = false;
+                if constexpr (HAS_BC) {
+                    m = pro_mask(pro, i, row, n0, n1);
+                    any = __builtin_amdgcn_ballot_w64((m.h | m.f) != 0u) != 0;
+                    if (any) {
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) U[n] = pro_flip(U[n], m.f, n);
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) U[8 + n] = pro_flip(U[8 + n], m.h, n), U[12 + n] = pro_flip(U[12 + n], m.h, n);
+                    }
+                }
+                source_prologue_field(pa, kf, hdt, U, U + 8, U + 12);
+                if constexpr (HAS_BC) {
+                    if (any) {
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) U[n] = pro_flip(U[n], m.f, n);
+                    }
+                }
+            }
+        };
+        auto slot_of = [&](int row) { return (row - row0) % FLD_NR; };
+        // a row into both sets' windows
+        auto put_row = [&](int slot, const double* U) {
+#pragma unroll
+            for (int n = 0; n < 8; ++n) ring[fgrp(n) * RG + (slot * 4 + fidx(n)) * 64 + lane] = U[n];
+        };
+
+        auto body = [&](auto GT) {
+            constexpr int G = decltype(GT)::value;
+            double* const ringG = ring + G * RG;
+            auto at = [&](int slot, int q, int l) -> double& { return ringG[(slot * 4 + q) * 64 + l]; };
+            auto expand = [&](const double* Q4, double m, double* Q10) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) Q10[n] = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Q10[fgc(G, q)] = Q4[q];
+                Q10[8] = Q10[9] = m;
+            };
+            auto pick = [&](const double* F10, double* F4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) F4[q] = F10[fgc(G, q)];
+            };
+            // the six rows of the prologue: this wave loads (and takes through stage A) those of its parity
+            // (rows alternate between the waves: row `row` is loaded by wave ((row - row0) & 1) ^ 1, so that in every
+            //  iteration one wave takes the entering row through stage A while the other finishes stage C of the row
+            //  that left)
+            double Un[NL];
+            for (int s = G ^ 1; s < FLD_NR; s += 2) {
+                load_row(row0 + s, Un);
+                enter(Un, row0 + s);
+                put_row(s, Un);
+            }
+            load_row(ja + 2 + (G ^ 1) < jb + 4 ? ja + 2 + (G ^ 1) : jb + 4, Un);  // this wave's next row
+            __syncthreads();
+            double Iy_p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Iy_p[q] = o6_interface(at(0, q, lane), at(1, q, lane), at(2, q, lane), at(3, q, lane), at(4, q, lane), at(5, q, lane));
+            double xlo_p[4], xhi_p[4], yhiU_p[4], yhiC_p[4], fy_p[4], fy2_p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xlo_p[q] = xhi_p[q] = yhiU_p[q] = yhiC_p[q] = fy_p[q] = fy2_p[q] = 0.0;
+            double sp[SRC > 0 ? SRC : 1][5];
+#pragma unroll
+            for (int s = 0; s < (SRC > 0 ? SRC : 1); ++s)
+#pragma unroll
+                for (int n = 0; n < 5; ++n) sp[s][n] = 1.0;
+
+            // stage C of row `row`, whose updated values the previous iteration left in the exchange row
+            auto finish_row = [&](int row) {
+                if constexpr (SRC > 0) {
+                    if (upd && row >= ja && row <= jb) {
+                        const long c = col + (long)row * g.sj;
+                        double Unew[10];
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) Unew[n] = xchg[n * 64 + lane];
+                        Unew[8] = Unew[9] = 1.0;  // mu, ep: F = 0 (MFP_field_RH.cpp:33), vacuum block
+                        source_epilogue_cell_pre<SRC>(g, epi, dt, c, Unew, sp, src_speed, src_dt);
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) Uout[c + n * g.sc] = Unew[n];
+                    }
+                }
+            };
+            auto march_row = [&](const int r) __attribute__((always_inline)) {
+                const bool live = r <= jb + 1;
+                __syncthreads();  // both waves have finished reading the slot that is overwritten; the exchange row is written
+                if ((((r + 3 - row0) & 1) ^ 1) == G) {
+                    // row r + 3 enters the windows (it replaces row r - 3), row r + 5 is requested; the species of row
+                    // r - 1, whose stage C is this wave's in the next iteration, are requested too
+                    enter(Un, r + 3 < jb + 4 ? r + 3 : jb + 4);
+                    put_row(slot_of(r + 3), Un);
+                    load_row(r + 5 < jb + 4 ? r + 5 : jb + 4, Un);
+                    if constexpr (SRC > 0) {
+                        if (upd && r - 1 >= ja && r - 1 <= jb) source_epilogue_load<SRC>(g, epi, col + (long)(r - 1) * g.sj, sp);
+                    }
+                } else {
+                    finish_row(r - 2);  // updated by the previous iteration
+                }
+                __syncthreads();
+                const int s0 = slot_of(r - 2), s1 = slot_of(r - 1), s2 = slot_of(r), s3 = slot_of(r + 1), s4 = slot_of(r + 2),
+                          s5 = slot_of(r + 3);
+                // ---- A: y interface values, face states and half-step trace of row r
+                double ylo[4], yhi[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double centre = at(s2, q, lane);
+                    const double Iy = o6_interface(at(s0, q, lane), at(s1, q, lane), centre, at(s3, q, lane), at(s4, q, lane), at(s5, q, lane));
+                    ylo[q] = Iy_p[q];
+                    yhi[q] = Iy;
+                    Iy_p[q] = Iy;
+                    trace_faces(speed, hy, centre, ylo[q], yhi[q]);
+                }
+                // ---- B, C: sweep 1 on the low y-face of (i, r); x-face states of row r - 1 corrected with F_y(r - 1) - F_y(r),
+                //      domain-face rules, sweep 2 in x for row r - 1
+                double fx2[4];
+                {
+                    double fy[4];
+                    {
+                        double L[10], Rr[10], F[10];
+                        expand(yhiU_p, mhi[1], L);
+                        expand(ylo, mlo[1], Rr);
+                        Phys::riemann(P, 1, L, Rr, F);
+                        pick(F, fy);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) yhiU_p[q] = yhi[q];
+                    {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const double dF = fy_p[q] - fy[q];
+                            xhi_p[q] += hy * dF;
+                            xlo_p[q] += hy * dF;
+                        }
+                        double L4[4], L[10], Rr[10], F[10];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) L4[q] = lane_left(xhi_p[q]);
+                        expand(L4, mhi[0], L);
+                        expand(xlo_p, mlo[0], Rr);
+                        if (HAS_BC && bc.touch[0][0] && i == 0) {
+#pragma unroll
+                            for (int n = 0; n < 10; ++n)
+                                if (bc.rule[0][0][n]) L[n] = bc.rule[0][0][n] == FILL_ODD ? -Rr[n] : Rr[n];
+                        }
+                        if (HAS_BC && bc.touch[0][1] && i == n0) {
+#pragma unroll
+                            for (int n = 0; n < 10; ++n)
+                                if (bc.rule[0][1][n]) Rr[n] = bc.rule[0][1][n] == FILL_ODD ? -L[n] : L[n];
+                        }
+                        Phys::riemann(P, 0, L, Rr, F);
+                        pick(F, fx2);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fy_p[q] = fy[q];
+                }
+                // ---- D: x interface values, face states, trace and sweep 1 of row r; y-face states corrected with F_x(i) - F_x(i + 1)
+                {
+                    double xlo[4], xhi[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double centre = at(s2, q, lane);
+                        const double Ix = o6_interface(at(s2, q, lane - 2), at(s2, q, lane - 1), centre, at(s2, q, lane + 1), at(s2, q, lane + 2),
+                                                       at(s2, q, lane + 3));
+                        xlo[q] = lane_left(Ix);
+                        xhi[q] = Ix;
+                        trace_faces(speed, hx, centre, xlo[q], xhi[q]);
+                    }
+                    double fx[4];
+                    {
+                        double L4[4], L[10], Rr[10], F[10];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) L4[q] = lane_left(xhi[q]);
+                        expand(L4, mhi[0], L);
+                        expand(xlo, mlo[0], Rr);
+                        Phys::riemann(P, 0, L, Rr, F);
+                        pick(F, fx);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        xlo_p[q] = xlo[q];
+                        xhi_p[q] = xhi[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double dF = fx[q] - lane_right(fx[q]);
+                        yhi[q] += hx * dF;
+                        ylo[q] += hx * dF;
+                    }
+                }
+                // ---- E: domain-face rules + sweep 2 on the low y-face of (i, r)
+                double fy2[4];
+                {
+                    double L[10], Rr[10], F[10];
+                    expand(yhiC_p, mhi[1], L);
+                    expand(ylo, mlo[1], Rr);
+                    if (HAS_BC && bc.touch[1][0] && r == 0) {
+#pragma unroll
+                        for (int n = 0; n < 10; ++n)
+                            if (bc.rule[1][0][n]) L[n] = bc.rule[1][0][n] == FILL_ODD ? -Rr[n] : Rr[n];
+                    }
+                    if (HAS_BC && bc.touch[1][1] && r == n1) {
+#pragma unroll
+                        for (int n = 0; n < 10; ++n)
+                            if (bc.rule[1][1][n]) Rr[n] = bc.rule[1][1][n] == FILL_ODD ? -L[n] : L[n];
+                    }
+                    Phys::riemann(P, 1, L, Rr, F);
+                    pick(F, fy2);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) yhiC_p[q] = yhi[q];
+                // ---- F: divergence of row r - 1, new += dU, [stage C by the wave of the row's parity]
+                {
+                    double Un4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double fxh = lane_right(fx2[q]);
+                        double du = 0.0;
+                        du += dtdx * (fx2[q] - fxh);
+                        du += dtdy * (fy2_p[q] - fy2[q]);
+                        Un4[q] = at(s1, q, lane) + du;
+                    }
+                    const long c = col + (long)(r - 1) * g.sj;
+                    if constexpr (SRC > 0) {  // left for the other wave, which finishes the row in the next iteration
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xchg[fgc(G, q) * 64 + lane] = Un4[q];
+                    } else {
+                        if (upd && live && r > ja) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) Uout[c + fgc(G, q) * g.sc] = Un4[q];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fy2_p[q] = fy2[q];
+            };
+            int r = ja - 1;
+            for (; r <= jb + 1; r += 2) {
+                march_row(r);
+                march_row(r + 1);
+            }
+            if constexpr (SRC > 0) {  // the row the last iteration (r - 1) updated
+                __syncthreads();
+                if ((((r + 3 - row0) & 1) ^ 1) != G) finish_row(r - 2);
+            }
+        };
+        if (grp == 0)
+            body(FldSet<0>{});
+        else
+            body(FldSet<1>{});
+    }
+    if constexpr (SRC > 0) {
+        __syncthreads();  // the windows are free
+        source_epilogue_reduce<SRC>(epi, src_speed, src_dt, ring, tid, 2, (int)(blockIdx.x & 255));
+    }
+}
+
 // one flag word: 0 if every valid cell has mu == 1 and ep == 1 (set to 1 by any cell that has not); *flag must be
 // zero before the launch
 __global__ void k_fld_vacuum(Geo g, const double* __restrict__ U, int* flag) {
@@ -435,6 +776,24 @@ int ctu_march_field(const Geo& g, const StatePhys& sp, const double* Uin, double
     const dim3 grid(((sel.nwaves + 7) / 8) * 8), block(64);
     SourcePro pr;
     std::memset(&pr, 0, sizeof(pr));
+    // two waves per strip (k_fld_pair) with CMFP_FIELD_PAIR=1: measured slower than one (see the kernel's comment)
+    static const bool pair = std::getenv("CMFP_FIELD_PAIR") && std::atoi(std::getenv("CMFP_FIELD_PAIR")) == 1;
+    if (pair) {
+        const dim3 block2(128);
+#define FLDP(BC, NS, PR, E) hipLaunchKernelGGL((k_fld_pair<BC, NS, PR>), grid, block2, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, E, pr)
+        if (pro) {
+            pr = *pro;
+            if (has_bc) FLDP(true, 2, true, *epi); else FLDP(false, 2, true, *epi);
+        } else if (epi && epi->ns == 2) {
+            if (has_bc) FLDP(true, 2, false, *epi); else FLDP(false, 2, false, *epi);
+        } else if (epi && epi->ns == 1) {
+            if (has_bc) FLDP(true, 1, false, *epi); else FLDP(false, 1, false, *epi);
+        } else {
+            if (has_bc) FLDP(true, 0, false, NoEpi{}); else FLDP(false, 0, false, NoEpi{});
+        }
+#undef FLDP
+        return 1;
+    }
 #define FLD(BC, NS, E) hipLaunchKernelGGL((k_fld_march<BC, NS, false>), grid, block, 0, st, g, sp.fp, Uin, Uout, dt, bc, sel, E, pr)
     if (pro) {
         pr = *pro;

@@ -124,6 +124,39 @@ def test_prologue_with_the_hybrid_flux(oracle, mode, faces):
     a.close()
 
 
+@pytest.mark.parametrize("faces", ["pp", "pw", "wo"])
+def test_field_update_by_a_pair_of_waves(oracle, monkeypatch, faces):
+    """CMFP_FIELD_PAIR=1: the TE / TM halves of the field update on two waves per strip (k_fld_pair), stages A and C
+    alternating between them — the same bits as the oracle (STRICT) with the prologue, with the epilogue only and
+    without a source action; FAST the same bits as the one-wave kernel."""
+    monkeypatch.setenv("CMFP_FIELD_PAIR", "1")      # read at the library's first field launch: its own process state
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+        import numpy as np
+        from cerberus_amd import abi, config
+        from oracle import oracle
+        import test_gpu_prologue as T
+        for source in ("plasma5", None):
+            for prologue in (True, False):
+                cfg = T._ot(130, 70, faces={faces!r})
+                if source is None:
+                    del cfg["actions"]["plasma"]
+                P = config.Problem(cfg, fp_mode=abi.FP_STRICT)
+                ref = oracle.OracleSim(P, max_grid_size=32)
+                dts_ref = ref.run(5)
+                m = T._gpu(P, prologue=prologue)
+                assert m.run(5) == dts_ref and m.last_advance_path() == 1
+                for s in range(m.n_states):
+                    assert np.array_equal(m.download(s), ref.get_state(s)), (source, prologue, P.state_names[s])
+                m.close()
+        print("pair ok")
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, CMFP_FIELD_PAIR="1"))
+    assert out.returncode == 0 and "pair ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_strict_prologue_with_denormal_components(oracle):
     """components the source does not touch pass through the reference's 0.5 x + 0.5 x (MFP_advance.cpp:194), which
     changes a subnormal value with an odd last bit: the prologue does the same (rho of the species, B of the field)"""
