@@ -36,7 +36,8 @@ WORKLOAD_NOTE = {"ot2f_2d": "BASELINE configs[2]: 2D two-fluid Orszag-Tang, plas
                  "gem_2d": "BASELINE configs[3]: 2D GEM reconnection two-fluid + Maxwell, walls in y; 8 GPUs x 4096x2048 = 8192^2"}
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
 PROFILE_ROUND = "r03"                         # profiles/<round>/pmc_<tag>.json: PMC traffic per launch of the kept profiles
-PROFILE_TAG = {("ot2f_2d", 4096): "ot2f_4096", ("kh_2d", 2048): "kh_2048", ("gem_2d", 4096): "gem_4096", ("rmi_3d", 256): "rmi3d_256"}
+PROFILE_TAG = {("ot2f_2d", 4096): "ot2f_4096", ("kh_2d", 2048): "kh_2048", ("gem_2d", 4096): "gem_4096", ("rmi_3d", 256): "rmi3d_256",
+               ("rmi_3d", 512): "rmi3d_512"}
 
 
 def block_cells(workload, n):
