@@ -11,6 +11,8 @@ ran that combination (wrap-both or wrap-none, prologue up to 2048 x 520).  Here 
   FAB-level functions one to one and are bit-identical to the oracle at every size the oracle reaches);
 * species mass is conserved to rounding on the periodic domain (through the walls of the GEM block too);
 * the same for the GEM block 4096 x 2048 (BASELINE configs[3] per GPU): y ghost-fill launch, x wrapped.
+* the other two single-GPU legs of the bench at their sizes: Kelvin-Helmholtz 2048^2 (configs[1]) and Richtmyer-Meshkov
+  256^3 (configs[4] reduced; 512^3 runs the same kernels) — FAST fused against STRICT staged, per component.
 The oracle itself is too slow at this size (0.6 M cell-updates/s per core); a small oracle case of the y-only wrap
 is in test_gpu_wrap.py."""
 import numpy as np
@@ -101,3 +103,45 @@ def test_orszag_tang_4096_fast_default_path():
 def test_gem_block_4096x2048_fast_default_path():
     worst = _check(lambda: problems.gem_reconnection_2d(4096, 2048), 1, walls=True)      # bit 0: x wrapped, walls in y
     print(f"gem 4096x2048 FAST (bench path) vs STRICT staged after {STEPS} steps: worst per-component rel L-inf {worst:.2e}")
+
+
+def _fast_vs_strict(make, steps):
+    """FAST on the fused kernels against STRICT on the stage-by-stage kernels: worst per-component rel L-inf"""
+    P, m, dts, info = _run(make(), abi.FP_FAST, True, steps)
+    assert info["path"] != 0, "fused kernels"
+    fast = [m.download(s) for s in range(m.n_states)]
+    m.close()
+    P2, r, dts_ref, info_ref = _run(make(), abi.FP_STRICT, False, steps)
+    assert info_ref["path"] == 0
+    np.testing.assert_allclose(dts, dts_ref, rtol=1e-12)
+    worst = 0.0
+    for s in range(r.n_states):
+        e = rel_linf_per_comp(fast[s], r.download(s))
+        assert e.max() <= TOL, (P.state_names[s], e.tolist())
+        worst = max(worst, float(e.max()))
+    r.close()
+    return P, fast, info, worst
+
+
+def test_kelvin_helmholtz_2048_fast_default_path():
+    """BASELINE configs[1] (the pure flux stencil): both directions wrapped inside the marching kernel, no ghost-fill
+    launch; mass, momentum and energy conserved to rounding on the periodic domain"""
+    P, fast, info, worst = _fast_vs_strict(lambda: problems.kelvin_helmholtz_2d(2048), 6)
+    assert info["path"] == 1 and info["wrapped"] == 3, info
+    U0 = P.initial_data(0)
+    for c in (0, 4):
+        a, b = U0[c].sum(dtype=np.longdouble), fast[0][c].sum(dtype=np.longdouble)
+        assert abs(b - a) <= 1e-12 * abs(a), (c, float((b - a) / a))
+    for c in (1, 2):   # momenta: sums near zero by symmetry, measured against the sum of magnitudes
+        a, b = U0[c].sum(dtype=np.longdouble), fast[0][c].sum(dtype=np.longdouble)
+        assert abs(b - a) <= 1e-12 * np.abs(U0[c]).sum(dtype=np.longdouble), c
+    print(f"kh 2048^2 FAST (bench path) vs STRICT staged: worst per-component rel L-inf {worst:.2e}")
+
+
+def test_richtmyer_meshkov_256_fast_default_path():
+    """BASELINE configs[4] at the size of the bench's reduced leg (256^3; the 512^3 leg runs the same kernels):
+    z-marching hydro kernel, three-pass field update with stage C as its epilogue, stage A a launch of its own"""
+    P, fast, info, worst = _fast_vs_strict(lambda: problems.richtmyer_meshkov_3d(256), 3)
+    assert info["fusion"] == 2, info
+    assert np.all(fast[P.state_names.index("field")][8] == 1.0)
+    print(f"rmi 256^3 FAST (bench path) vs STRICT staged: worst per-component rel L-inf {worst:.2e}")
