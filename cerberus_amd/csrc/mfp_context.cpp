@@ -61,7 +61,8 @@ struct StateRT {
     double* tab_cell[3][2][CMFP_MAX_COMP] = {};
     double* tab_face[3][2][CMFP_MAX_COMP] = {};
     bool has_tables = false;
-    double* dyn[CMFP_MAX_COMP] = {};  // 'dynamic' components (cmfp_state_set_dynamic): values over the ghosted block
+    double* dyn[CMFP_MAX_COMP] = {};      // 'dynamic' components (cmfp_state_set_dynamic): values over the ghosted block
+    double* dyn_buf[CMFP_MAX_COMP] = {};  // their allocations (kept when an entry is removed, reused when it returns)
     bool has_dynamic = false;
     // field: the materials check (mu == ep == 1 everywhere) has been made for the data now in new_data;
     // the ping-pong partner holds mu, ep too (the vacuum kernel neither reads nor rewrites them)
@@ -1969,8 +1970,8 @@ int cmfp_state_set_dynamic(cmfp_context* c, int s, int comp, const double* value
     if (!values) {
         st.dyn[comp] = nullptr;  // (freed with the context)
     } else {
-        double*& d = st.dyn[comp];
-        if ((r = dalloc(c, &d, c->g.sc))) return r;
+        if ((r = dalloc(c, &st.dyn_buf[comp], c->g.sc))) return r;
+        double* d = st.dyn[comp] = st.dyn_buf[comp];
         HIPCHK(c, hipMemcpyAsync(d, values, sizeof(double) * c->g.sc, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer may be reused on return
     }

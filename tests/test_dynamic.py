@@ -86,11 +86,11 @@ def test_oracle_rk2_takes_the_override_into_the_state(oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("scheme", ["strang", "RK2", "euler"])
 def test_dynamic_component_parity(oracle, scheme):
-    """HIP path (stage-by-stage kernels) against the oracle, time-dependent function (strang) / constant function
-    (euler, RK2: time-dependent tables are refused off strang by the driver as for the boundary functions)."""
+    """HIP path (stage-by-stage kernels) against the oracle with a function of (x, y, t): tabulated at time + dt for
+    the Strang flux stage, at time for both stages of euler / RK2 (MFP_advance.cpp:72-104,208-217)."""
     from cerberus_amd.mfp import MFP
     for mode, tol in ((abi.FP_STRICT, 0.0), (abi.FP_FAST, 1e-12)):
-        P = _problem(scheme, fp_mode=mode, time_dependent=(scheme == "strang"))
+        P = _problem(scheme, fp_mode=mode, time_dependent=True)
         ref = oracle.OracleSim(P)
         m = MFP(P)
         m.init_data()
