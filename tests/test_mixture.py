@@ -361,6 +361,33 @@ def test_mixture_with_elliptic_action_gpu(oracle, mode):
 
 
 @pytest.mark.gpu
+def test_mixture_ions_in_collisions_beside_plasma5(oracle):
+    """two-fluid Orszag-Tang, Strang: the ions a mixture of two kinds, the second of which collides with the electrons
+    (collisions_rambo beside plasma5; stage-by-stage kernels).  Coulomb branch: pow(x, -1.5) of the device library
+    against glibc's, hence 1e-13 in STRICT."""
+    cfg = problems.orszag_tang_two_fluid_2d(24, collisions=True)
+    problems.with_mixture(cfg, "ion", [lambda d: 0.4 + 0.2 * np.sin(d["x"])], [1.0, 2.0], [5 / 3, 1.4], [1.0, 2.0])
+    cfg["actions"]["collisions"]["species"] = ["ion_1", "electron"]
+    for mode, tol in ((abi.FP_STRICT, 1e-13), (abi.FP_FAST, 1e-12)):
+        P = config.Problem(cfg, fp_mode=mode)
+        ref = oracle.OracleSim(P)
+        dts_ref = ref.run(4)
+        m = _gpu(P)
+        dts = m.run(4)
+        assert m.last_advance_path() == 0
+        np.testing.assert_allclose(dts, dts_ref, rtol=1e-12)
+        for s in range(3):
+            assert rel_linf(m.download(s), ref.get_state(s)) <= tol, (mode, P.state_names[s])
+        # the collisions do something: the same run without them differs
+        m.close()
+    c2 = problems.orszag_tang_two_fluid_2d(24)
+    problems.with_mixture(c2, "ion", [lambda d: 0.4 + 0.2 * np.sin(d["x"])], [1.0, 2.0], [5 / 3, 1.4], [1.0, 2.0])
+    r2 = oracle.OracleSim(config.Problem(c2))
+    r2.run(4)
+    assert rel_linf(r2.get_state(0), ref.get_state(0)) > 1e-9
+
+
+@pytest.mark.gpu
 def test_mixture_refusals_of_the_library():
     """a collisions species that names no sub-component of its state: CMFP_ERR_INVALID, nothing silently approximated
     (a mixture in a collisions action itself is built: tests/test_gpu_actions.py::test_collisions_sub_component_parity)"""
