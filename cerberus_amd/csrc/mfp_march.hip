@@ -54,12 +54,12 @@ struct MarchStates {
 // (MFP_hydro.cpp:982-995), the tracer fluxes of HLLC / HLLE from the side and wave speeds of the hydro solve
 // (MFP_hllc.cpp:100-183, MFP_hydro_hlle.cpp:75-118), transverse corrections as tracer = alpha rho, += k dF,
 // alpha = tracer / rho' (prim2cons / cons2prim, MFP_thermally_perfect_gas.cpp:212-214,243-245).  These instances
-// hold about 60 more values per lane and run at one wave per SIMD.
+// hold about 60 more values per lane and run at one wave per SIMD.  The source prologue leaves them alone.
 template <class Phys, bool HAS_BC, bool REDUCE, bool PRO, bool TAB = false, int NT = 0>
 __global__ __launch_bounds__(64, (NT || (PRO && Phys::FLUX == 2)) ? 1 : 2) void k_ctu_march(Geo g, MarchStates<Phys> S, double dt, MarchBC bc, int* err, MarchSel sel,
                                                                SourcePro pro, MarchTab tab) {
     static_assert(!TAB || (HAS_BC && !PRO), "face tables: blocks with physical faces, no source prologue");
-    static_assert(NT == 0 || (!PRO && !TAB), "passive scalars: no source prologue, no face tables");
+    static_assert(NT == 0 || !TAB, "passive scalars: no face tables");
     constexpr int NTA = NT ? NT : 1;  // array lengths (no zero-length arrays)
     constexpr int RECON = Phys::RECON;
     static_assert(ReconTraits<RECON>::SL == 3 && Phys::IS_HYDRO, "three-point hydro reconstructions");
@@ -594,7 +594,7 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
     // passive scalars (species of equal mass / gamma): their own kernel instances; true mixtures (per-cell gamma), the
     // hybrid flux (no tracer flux in the reference, Q5), the prologue and face tables stay outside
     const int nt = sp[0]->hp.nt;
-    if (nt && (sp[0]->hp.mix || Phys::FLUX == 2 || pro || tabs || nt > 2)) return 0;
+    if (nt && (sp[0]->hp.mix || Phys::FLUX == 2 || tabs || nt > 2)) return 0;
     if (n == 2 && sp[1]->hp.nt != nt) return 0;
     if (!Uin[0]) return part == 1 ? has_int : 1;
     const MarchBC bc = make_march_bc(*sp[0], touches);
@@ -621,6 +621,14 @@ static int launch_march(const Geo& g, int n, const StatePhys* const sp[2], const
         return 1;
     }
     if constexpr (Phys::FLUX != 2) {
+        if (nt && pro) {  // the source terms do not touch the mass fractions: the prologue instance with the tracer lanes
+            pr = *pro;
+            if (nt == 1)
+                hipLaunchKernelGGL((k_ctu_march<Phys, true, false, true, false, 1>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb);
+            else
+                hipLaunchKernelGGL((k_ctu_march<Phys, true, false, true, false, 2>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb);
+            return 1;
+        }
         if (nt) {  // (always the instance with the face rules: half as many kernels to build)
 #define CMFP_LAUNCH_T(RED, NTV) \
     hipLaunchKernelGGL((k_ctu_march<Phys, true, RED, false, false, NTV>), grid, block, 0, st, g, S, dt, bc, err, sel, pr, tb)

@@ -537,6 +537,7 @@ def test_tracers_on_the_marching_kernel_at_size(oracle, n, nt):
         m = _gpu(P)
         dts = m.run(4)
         assert m.last_advance_path() == 1
+        assert m.last_source_fusion() == 3      # stage A as the prologue of the tracer instances too, stage C the field's epilogue
         for s in range(3):
             a, b = m.download(s), ref.get_state(s)
             if tol == 0.0:
